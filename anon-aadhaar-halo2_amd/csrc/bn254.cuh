@@ -1,0 +1,405 @@
+// BN254 field and G1 arithmetic for gfx950 (and the host side of the product path).
+//
+// Replaces, on the device, what the reference reaches through
+//   halo2curves 0.3.1 bn256::{Fr,Fq,G1,G1Affine}   (Cargo.lock:484-486).
+// Number format is halo2curves' in-memory format: little-endian limbs, Montgomery form with
+// R = 2^256, so a Rust `&[Fr]` / `&[G1Affine]` slice can be handed over byte-for-byte.
+// A 4 x u64 little-endian value is the same 32 bytes as the 8 x u32 used here.
+//
+// Layout choice for CDNA4: 8 x 32-bit limbs. The only wide multiplier the VALU has is
+// v_mad_u64_u32 (32x32+64 -> 64); every product below is written so that hipcc emits it.
+// Moduli are < 2^254, so the CIOS Montgomery loop never needs the 10th carry word.
+//
+// All functions are __host__ __device__: the host uses them for the O(1)/O(columns) glue
+// (normalising a handful of points, domain constants), never for O(n) work.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define ZK_HD __host__ __device__ __forceinline__
+#define ZK_D __device__ __forceinline__
+#else
+#define ZK_HD inline
+#define ZK_D inline
+#endif
+
+namespace bn254 {
+
+struct FqP {
+  static ZK_HD constexpr uint32_t p(int i) {
+    constexpr uint32_t v[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
+                               0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    return v[i];
+  }
+  static ZK_HD constexpr uint32_t r1(int i) {  // R mod p  (Montgomery one)
+    constexpr uint32_t v[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
+                               0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+    return v[i];
+  }
+  static ZK_HD constexpr uint32_t r2(int i) {  // R^2 mod p
+    constexpr uint32_t v[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u,
+                               0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+    return v[i];
+  }
+  static constexpr uint32_t inv = 0xe4866389u;  // -p^{-1} mod 2^32
+};
+
+struct FrP {
+  static ZK_HD constexpr uint32_t p(int i) {
+    constexpr uint32_t v[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
+                               0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    return v[i];
+  }
+  static ZK_HD constexpr uint32_t r1(int i) {
+    constexpr uint32_t v[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,
+                               0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+    return v[i];
+  }
+  static ZK_HD constexpr uint32_t r2(int i) {
+    constexpr uint32_t v[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u,
+                               0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+    return v[i];
+  }
+  static constexpr uint32_t inv = 0xefffffffu;
+};
+
+template <class P>
+struct alignas(16) Fp {
+  uint32_t l[8];
+
+  static ZK_HD Fp zero() {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = 0;
+    return r;
+  }
+  static ZK_HD Fp one() {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = P::r1(i);
+    return r;
+  }
+  static ZK_HD Fp r2() {
+    Fp r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = P::r2(i);
+    return r;
+  }
+  ZK_HD bool is_zero() const {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= l[i];
+    return o == 0;
+  }
+  ZK_HD bool operator==(const Fp& b) const {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= l[i] ^ b.l[i];
+    return o == 0;
+  }
+  ZK_HD bool operator!=(const Fp& b) const { return !(*this == b); }
+};
+
+// r = a - p if a >= p else a   (a < 2p)
+template <class P>
+ZK_HD Fp<P> reduce_once(const Fp<P>& a) {
+  Fp<P> d;
+  uint32_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t t = (uint64_t)a.l[i] - P::p(i) - borrow;
+    d.l[i] = (uint32_t)t;
+    borrow = (uint32_t)(t >> 63);
+  }
+  Fp<P> r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.l[i] = borrow ? a.l[i] : d.l[i];
+  return r;
+}
+
+template <class P>
+ZK_HD Fp<P> add(const Fp<P>& a, const Fp<P>& b) {
+  Fp<P> s;
+  uint32_t carry = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t t = (uint64_t)a.l[i] + b.l[i] + carry;
+    s.l[i] = (uint32_t)t;
+    carry = (uint32_t)(t >> 32);
+  }
+  // p < 2^254 so a+b < 2^255: no carry out of limb 7.
+  return reduce_once(s);
+}
+
+template <class P>
+ZK_HD Fp<P> sub(const Fp<P>& a, const Fp<P>& b) {
+  Fp<P> d;
+  uint32_t borrow = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t t = (uint64_t)a.l[i] - b.l[i] - borrow;
+    d.l[i] = (uint32_t)t;
+    borrow = (uint32_t)(t >> 63);
+  }
+  uint32_t mask = 0u - borrow;
+  uint32_t carry = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t t = (uint64_t)d.l[i] + (P::p(i) & mask) + carry;
+    d.l[i] = (uint32_t)t;
+    carry = (uint32_t)(t >> 32);
+  }
+  return d;
+}
+
+template <class P>
+ZK_HD Fp<P> neg(const Fp<P>& a) {
+  return sub(Fp<P>::zero(), a);
+}
+
+template <class P>
+ZK_HD Fp<P> dbl(const Fp<P>& a) {
+  return add(a, a);
+}
+
+// Montgomery product a*b*R^-1 mod p, CIOS over 32-bit limbs.
+// Invariant: after every outer iteration t < 2p < 2^255, so t fits 8 limbs + a zero 9th.
+template <class P>
+ZK_HD Fp<P> mul(const Fp<P>& a, const Fp<P>& b) {
+  uint32_t t[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint32_t bi = b.l[i];
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      c = (uint64_t)a.l[j] * bi + t[j] + c;
+      t[j] = (uint32_t)c;
+      c >>= 32;
+    }
+    uint32_t t8 = (uint32_t)c;  // 9th limb (the 9th limb of t itself is always 0 here)
+    uint32_t m = t[0] * P::inv;
+    c = ((uint64_t)m * P::p(0) + t[0]) >> 32;
+#pragma unroll
+    for (int j = 1; j < 8; j++) {
+      c = (uint64_t)m * P::p(j) + t[j] + c;
+      t[j - 1] = (uint32_t)c;
+      c >>= 32;
+    }
+    t[7] = (uint32_t)c + t8;  // < 2^32 because the shifted sum is < 2p < 2^255
+  }
+  Fp<P> r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.l[i] = t[i];
+  return reduce_once(r);
+}
+
+template <class P>
+ZK_HD Fp<P> sqr(const Fp<P>& a) {
+  return mul(a, a);
+}
+
+template <class P>
+ZK_HD Fp<P> to_mont(const Fp<P>& a) {
+  return mul(a, Fp<P>::r2());
+}
+template <class P>
+ZK_HD Fp<P> from_mont(const Fp<P>& a) {
+  Fp<P> o = Fp<P>::zero();
+  o.l[0] = 1;
+  return mul(a, o);
+}
+
+// a^e, e given as 8 x u32 little endian (plain integer). Variable time.
+template <class P>
+ZK_HD Fp<P> pow_u256(const Fp<P>& a, const uint32_t e[8]) {
+  Fp<P> r = Fp<P>::one();
+  bool started = false;
+  for (int i = 7; i >= 0; i--) {
+    for (int b = 31; b >= 0; b--) {
+      if (started) r = sqr(r);
+      if ((e[i] >> b) & 1) {
+        r = started ? mul(r, a) : a;
+        started = true;
+      }
+    }
+  }
+  return r;
+}
+
+template <class P>
+ZK_HD Fp<P> pow_u64(const Fp<P>& a, uint64_t e) {
+  uint32_t ee[8] = {(uint32_t)e, (uint32_t)(e >> 32), 0, 0, 0, 0, 0, 0};
+  return pow_u256(a, ee);
+}
+
+// Fermat inverse a^(p-2); inv(0) = 0.
+template <class P>
+ZK_HD Fp<P> inv(const Fp<P>& a) {
+  uint32_t e[8];
+  uint32_t borrow = 2;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t t = (uint64_t)P::p(i) - borrow;
+    e[i] = (uint32_t)t;
+    borrow = (uint32_t)(t >> 63);
+  }
+  return pow_u256(a, e);
+}
+
+using Fr = Fp<FrP>;
+using Fq = Fp<FqP>;
+
+// ---------------------------------------------------------------- G1: y^2 = x^3 + 3
+// Affine point; (0,0) is the identity (halo2curves G1Affine convention).
+struct alignas(16) G1Affine {
+  Fq x, y;
+  ZK_HD bool is_inf() const { return x.is_zero() && y.is_zero(); }
+};
+
+// Jacobian point as halo2curves G1 {x,y,z}; z = 0 is the identity.
+struct alignas(16) G1Jac {
+  Fq x, y, z;
+};
+
+// Extended Jacobian ("XYZZ"): x = X/ZZ, y = Y/ZZZ with ZZ^3 = ZZZ^2. ZZ = 0 is the identity.
+// Used for bucket accumulators: mixed add costs 8M+2S and needs no inversion.
+struct alignas(16) G1X {
+  Fq x, y, zz, zzz;
+  static ZK_HD G1X inf() {
+    G1X r;
+    r.x = Fq::zero();
+    r.y = Fq::zero();
+    r.zz = Fq::zero();
+    r.zzz = Fq::zero();
+    return r;
+  }
+  ZK_HD bool is_inf() const { return zz.is_zero(); }
+};
+
+ZK_HD G1X x_from_affine(const G1Affine& p) {
+  G1X r;
+  if (p.is_inf()) return G1X::inf();
+  r.x = p.x;
+  r.y = p.y;
+  r.zz = Fq::one();
+  r.zzz = Fq::one();
+  return r;
+}
+
+// 2*(affine) -> XYZZ  (mdbl-2008-s-1, a = 0)
+ZK_HD G1X x_dbl_affine(const G1Affine& p) {
+  if (p.is_inf()) return G1X::inf();
+  Fq u = dbl(p.y);
+  Fq v = sqr(u);
+  Fq w = mul(u, v);
+  Fq s = mul(p.x, v);
+  Fq xx = sqr(p.x);
+  Fq m = add(dbl(xx), xx);
+  G1X r;
+  r.x = sub(sqr(m), dbl(s));
+  r.y = sub(mul(m, sub(s, r.x)), mul(w, p.y));
+  r.zz = v;
+  r.zzz = w;
+  return r;
+}
+
+// 2*P in XYZZ (dbl-2008-s-1, a = 0)
+ZK_HD G1X x_dbl(const G1X& p) {
+  if (p.is_inf()) return p;
+  Fq u = dbl(p.y);
+  Fq v = sqr(u);
+  Fq w = mul(u, v);
+  Fq s = mul(p.x, v);
+  Fq xx = sqr(p.x);
+  Fq m = add(dbl(xx), xx);
+  G1X r;
+  r.x = sub(sqr(m), dbl(s));
+  r.y = sub(mul(m, sub(s, r.x)), mul(w, p.y));
+  r.zz = mul(v, p.zz);
+  r.zzz = mul(w, p.zzz);
+  return r;
+}
+
+// acc + affine q   (madd-2008-s), complete: handles acc = inf, q = inf, acc = q, acc = -q.
+ZK_HD G1X x_add_affine(const G1X& a, const G1Affine& q) {
+  if (q.is_inf()) return a;
+  if (a.is_inf()) return x_from_affine(q);
+  Fq u2 = mul(q.x, a.zz);
+  Fq s2 = mul(q.y, a.zzz);
+  Fq p = sub(u2, a.x);
+  Fq r = sub(s2, a.y);
+  if (p.is_zero()) {
+    if (r.is_zero()) return x_dbl_affine(q);
+    return G1X::inf();
+  }
+  Fq pp = sqr(p);
+  Fq ppp = mul(p, pp);
+  Fq qq = mul(a.x, pp);
+  G1X o;
+  o.x = sub(sub(sqr(r), ppp), dbl(qq));
+  o.y = sub(mul(r, sub(qq, o.x)), mul(a.y, ppp));
+  o.zz = mul(a.zz, pp);
+  o.zzz = mul(a.zzz, ppp);
+  return o;
+}
+
+// a + b, both XYZZ (add-2008-s), complete.
+ZK_HD G1X x_add(const G1X& a, const G1X& b) {
+  if (b.is_inf()) return a;
+  if (a.is_inf()) return b;
+  Fq u1 = mul(a.x, b.zz);
+  Fq u2 = mul(b.x, a.zz);
+  Fq s1 = mul(a.y, b.zzz);
+  Fq s2 = mul(b.y, a.zzz);
+  Fq p = sub(u2, u1);
+  Fq r = sub(s2, s1);
+  if (p.is_zero()) {
+    if (r.is_zero()) return x_dbl(a);
+    return G1X::inf();
+  }
+  Fq pp = sqr(p);
+  Fq ppp = mul(p, pp);
+  Fq qq = mul(u1, pp);
+  G1X o;
+  o.x = sub(sub(sqr(r), ppp), dbl(qq));
+  o.y = sub(mul(r, sub(qq, o.x)), mul(s1, ppp));
+  o.zz = mul(mul(a.zz, b.zz), pp);
+  o.zzz = mul(mul(a.zzz, b.zzz), ppp);
+  return o;
+}
+
+ZK_HD G1Affine a_neg(const G1Affine& p) {
+  G1Affine r;
+  r.x = p.x;
+  r.y = p.y.is_zero() ? p.y : neg(p.y);
+  return r;
+}
+
+ZK_HD G1X x_neg(const G1X& p) {
+  G1X r = p;
+  r.y = p.y.is_zero() ? p.y : neg(p.y);
+  return r;
+}
+
+// XYZZ -> Jacobian {x,y,z} with the same affine value: z = ZZZ/ZZ, so z^2 = ZZ, z^3 = ZZZ.
+// Needs one inversion; used only on the host for O(columns) results.
+ZK_HD G1Affine x_to_affine(const G1X& p) {
+  G1Affine r;
+  if (p.is_inf()) {
+    r.x = Fq::zero();
+    r.y = Fq::zero();
+    return r;
+  }
+  Fq izzz = inv(p.zzz);
+  Fq iz = mul(p.zz, izzz);   // 1/z  where z = zzz/zz
+  Fq izz = sqr(iz);          // 1/zz
+  r.x = mul(p.x, izz);
+  r.y = mul(p.y, izzz);
+  return r;
+}
+
+}  // namespace bn254

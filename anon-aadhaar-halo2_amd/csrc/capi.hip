@@ -1,0 +1,279 @@
+// C ABI of libamdzk (include/amdzk.h): context, device memory, and the host-pointer forms of the
+// hot-path entry points. Kernels live in ntt.hip / msm.hip. There is no CPU fallback here: every
+// entry point either runs on the gfx950 device or fails with a status code.
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.hpp"
+
+using namespace bn254;
+
+struct amdzk_srs;
+int zk_srs_upload(amdzk_ctx* ctx, const uint64_t* g, const uint64_t* g_lagrange, uint32_t k, amdzk_srs** out);
+void zk_srs_free(amdzk_ctx*, amdzk_srs* s);
+int zk_msm_dev_xyzz(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const Fr* d_scalars, size_t ncols,
+                    size_t len, size_t col_stride, G1X** d_out);
+int zk_msm_finish(amdzk_ctx* ctx, const G1X* d_res, size_t ncols, uint64_t* out_jac);
+
+static thread_local std::string g_init_err;
+
+int zk_ws_reserve(amdzk_ctx* ctx, int slot, size_t bytes, void** out) {
+  amdzk_ctx::Ws& w = ctx->ws[slot];
+  if (w.cap < bytes) {
+    if (w.p) {
+      ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      ZK_HIP(ctx, hipFree(w.p));
+      w.p = nullptr;
+      w.cap = 0;
+    }
+    size_t want = bytes + bytes / 8;
+    hipError_t e = hipMalloc(&w.p, want);
+    if (e != hipSuccess) {
+      want = bytes;
+      e = hipMalloc(&w.p, want);
+    }
+    if (e != hipSuccess) ZK_FAIL(ctx, AMDZK_E_NOMEM, "workspace %d: hipMalloc(%zu) failed: %s", slot, bytes, hipGetErrorString(e));
+    w.cap = want;
+  }
+  *out = w.p;
+  return AMDZK_OK;
+}
+
+int zk_pinned_reserve(amdzk_ctx* ctx, size_t bytes, void** out) {
+  if (ctx->h_pinned_cap < bytes) {
+    if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+    ctx->h_pinned = nullptr;
+    ctx->h_pinned_cap = 0;
+    size_t want = bytes < 65536 ? 65536 : bytes;
+    ZK_HIP(ctx, hipHostMalloc(&ctx->h_pinned, want, hipHostMallocDefault));
+    ctx->h_pinned_cap = want;
+  }
+  *out = ctx->h_pinned;
+  return AMDZK_OK;
+}
+
+hipEvent_t zk_evt_get(amdzk_ctx* ctx) {
+  if (!ctx->evt_pool.empty()) {
+    hipEvent_t e = ctx->evt_pool.back();
+    ctx->evt_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+
+void zk_prof_drain(amdzk_ctx* ctx) {
+  if (ctx->pending.empty()) return;
+  hipStreamSynchronize(ctx->stream);
+  for (auto& p : ctx->pending) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, p.a, p.b);
+    ProfEntry& e = ctx->prof_map[p.name];
+    e.launches++;
+    e.ms += ms;
+    ctx->evt_pool.push_back(p.a);
+    ctx->evt_pool.push_back(p.b);
+  }
+  ctx->pending.clear();
+}
+
+extern "C" {
+
+int amdzk_version(void) { return 1000; }
+
+int amdzk_init(int device_id, amdzk_ctx** out) {
+  if (!out) return AMDZK_E_INVALID;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_id < 0 || device_id >= count) return AMDZK_E_NO_DEVICE;
+  if (hipSetDevice(device_id) != hipSuccess) return AMDZK_E_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return AMDZK_E_NO_DEVICE;
+  // This library carries gfx950 code objects only.
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return AMDZK_E_NO_DEVICE;
+  amdzk_ctx* c = new amdzk_ctx();
+  c->device = device_id;
+  c->num_cu = prop.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return AMDZK_E_HIP;
+  }
+  c->stream = c->own_stream;
+  hipEventCreate(&c->t0);
+  hipEventCreate(&c->t1);
+  *out = c;
+  return AMDZK_OK;
+}
+
+void amdzk_destroy(amdzk_ctx* ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  zk_prof_drain(ctx);
+  for (auto& kv : ctx->twiddles) hipFree(kv.second);
+  for (auto& w : ctx->ws)
+    if (w.p) hipFree(w.p);
+  if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+  for (auto e : ctx->evt_pool) hipEventDestroy(e);
+  if (ctx->t0) hipEventDestroy(ctx->t0);
+  if (ctx->t1) hipEventDestroy(ctx->t1);
+  if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+const char* amdzk_last_error(const amdzk_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int amdzk_set_stream(amdzk_ctx* ctx, void* hip_stream) {
+  if (!ctx) return AMDZK_E_INVALID;
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return AMDZK_OK;
+}
+
+int amdzk_sync(amdzk_ctx* ctx) {
+  if (!ctx) return AMDZK_E_INVALID;
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AMDZK_OK;
+}
+
+int amdzk_dev_alloc(amdzk_ctx* ctx, size_t bytes, void** dptr) {
+  if (!ctx || !dptr) return AMDZK_E_INVALID;
+  hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+  if (e != hipSuccess) ZK_FAIL(ctx, AMDZK_E_NOMEM, "dev_alloc(%zu): %s", bytes, hipGetErrorString(e));
+  return AMDZK_OK;
+}
+int amdzk_dev_free(amdzk_ctx* ctx, void* dptr) {
+  if (!ctx) return AMDZK_E_INVALID;
+  if (!dptr) return AMDZK_OK;
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_HIP(ctx, hipFree(dptr));
+  return AMDZK_OK;
+}
+int amdzk_dev_upload(amdzk_ctx* ctx, void* dptr, const void* host, size_t bytes) {
+  if (!ctx || (!dptr && bytes) || (!host && bytes)) return AMDZK_E_INVALID;
+  ZK_HIP(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AMDZK_OK;
+}
+int amdzk_dev_download(amdzk_ctx* ctx, void* host, const void* dptr, size_t bytes) {
+  if (!ctx || (!dptr && bytes) || (!host && bytes)) return AMDZK_E_INVALID;
+  ZK_HIP(ctx, hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AMDZK_OK;
+}
+int amdzk_dev_memset(amdzk_ctx* ctx, void* dptr, int byte, size_t bytes) {
+  if (!ctx || (!dptr && bytes)) return AMDZK_E_INVALID;
+  ZK_HIP(ctx, hipMemsetAsync(dptr, byte, bytes, ctx->stream));
+  return AMDZK_OK;
+}
+
+int amdzk_srs_upload(amdzk_ctx* ctx, const uint64_t* g, const uint64_t* g_lagrange, uint32_t k, amdzk_srs** out) {
+  if (!ctx) return AMDZK_E_INVALID;
+  return zk_srs_upload(ctx, g, g_lagrange, k, out);
+}
+void amdzk_srs_free(amdzk_ctx* ctx, amdzk_srs* srs) {
+  if (ctx) hipStreamSynchronize(ctx->stream);
+  zk_srs_free(ctx, srs);
+}
+
+int amdzk_msm_g1_dev(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const void* d_scalars, size_t ncols,
+                     size_t len, size_t col_stride, uint64_t* out_jacobian) {
+  if (!ctx) return AMDZK_E_INVALID;
+  if (!d_scalars || !out_jacobian) ZK_FAIL(ctx, AMDZK_E_INVALID, "msm: null pointer");
+  G1X* d_res = nullptr;
+  ZK_TRY(zk_msm_dev_xyzz(ctx, srs, basis, (const Fr*)d_scalars, ncols, len, col_stride, &d_res));
+  return zk_msm_finish(ctx, d_res, ncols, out_jacobian);
+}
+
+int amdzk_msm_g1_batch(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const uint64_t* const* scalars,
+                       size_t ncols, size_t len, uint64_t* out_jacobian) {
+  if (!ctx) return AMDZK_E_INVALID;
+  if (!scalars || !out_jacobian || ncols == 0) ZK_FAIL(ctx, AMDZK_E_INVALID, "msm_batch: null pointer or ncols == 0");
+  Fr* d = nullptr;
+  size_t stride = len ? len : 1;
+  ZK_TRY(zk_ws_reserve(ctx, 2, ncols * stride * sizeof(Fr), (void**)&d));
+  for (size_t c = 0; c < ncols; c++) {
+    if (!scalars[c] && len) ZK_FAIL(ctx, AMDZK_E_INVALID, "msm_batch: column %zu is null", c);
+    ZK_HIP(ctx, hipMemcpyAsync(d + c * stride, scalars[c], len * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+  }
+  return amdzk_msm_g1_dev(ctx, srs, basis, d, ncols, len, stride, out_jacobian);
+}
+
+int amdzk_msm_g1(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const uint64_t* scalars, size_t len,
+                 uint64_t out_jacobian[12]) {
+  const uint64_t* cols[1] = {scalars};
+  return amdzk_msm_g1_batch(ctx, srs, basis, cols, 1, len, out_jacobian);
+}
+
+int amdzk_ntt_fr_dev(amdzk_ctx* ctx, void* d_a, uint32_t log_n, const uint64_t omega[4], uint32_t flags,
+                     size_t ncols, size_t col_stride) {
+  if (!ctx) return AMDZK_E_INVALID;
+  if (!d_a || !omega) ZK_FAIL(ctx, AMDZK_E_INVALID, "ntt: null pointer");
+  return zk_ntt_dev(ctx, (Fr*)d_a, log_n, omega, flags, ncols, col_stride);
+}
+
+int amdzk_ntt_fr(amdzk_ctx* ctx, uint64_t* a, uint32_t log_n, const uint64_t omega[4], uint32_t flags) {
+  if (!ctx) return AMDZK_E_INVALID;
+  if (!a || !omega) ZK_FAIL(ctx, AMDZK_E_INVALID, "ntt: null pointer");
+  if (log_n > 27) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "ntt: log_n %u > 27", log_n);
+  size_t bytes = ((size_t)1 << log_n) * sizeof(Fr);
+  Fr* d = nullptr;
+  ZK_TRY(zk_ws_reserve(ctx, 2, bytes, (void**)&d));
+  ZK_HIP(ctx, hipMemcpyAsync(d, a, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ZK_TRY(zk_ntt_dev(ctx, d, log_n, omega, flags, 1, (size_t)1 << log_n));
+  ZK_HIP(ctx, hipMemcpyAsync(a, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AMDZK_OK;
+}
+
+int amdzk_timer_start(amdzk_ctx* ctx) {
+  if (!ctx) return AMDZK_E_INVALID;
+  ZK_HIP(ctx, hipEventRecord(ctx->t0, ctx->stream));
+  return AMDZK_OK;
+}
+int amdzk_timer_stop(amdzk_ctx* ctx, float* ms) {
+  if (!ctx || !ms) return AMDZK_E_INVALID;
+  ZK_HIP(ctx, hipEventRecord(ctx->t1, ctx->stream));
+  ZK_HIP(ctx, hipEventSynchronize(ctx->t1));
+  ZK_HIP(ctx, hipEventElapsedTime(ms, ctx->t0, ctx->t1));
+  return AMDZK_OK;
+}
+int amdzk_prof_enable(amdzk_ctx* ctx, int on) {
+  if (!ctx) return AMDZK_E_INVALID;
+  zk_prof_drain(ctx);
+  ctx->prof = on != 0;
+  return AMDZK_OK;
+}
+int amdzk_prof_reset(amdzk_ctx* ctx) {
+  if (!ctx) return AMDZK_E_INVALID;
+  zk_prof_drain(ctx);
+  ctx->prof_map.clear();
+  return AMDZK_OK;
+}
+int amdzk_prof_get(amdzk_ctx* ctx, const char* kernel_name, uint64_t* launches, double* total_ms) {
+  if (!ctx || !kernel_name) return AMDZK_E_INVALID;
+  zk_prof_drain(ctx);
+  auto it = ctx->prof_map.find(kernel_name);
+  if (launches) *launches = it == ctx->prof_map.end() ? 0 : it->second.launches;
+  if (total_ms) *total_ms = it == ctx->prof_map.end() ? 0.0 : it->second.ms;
+  return AMDZK_OK;
+}
+size_t amdzk_prof_dump(amdzk_ctx* ctx, char* buf, size_t cap) {
+  if (!ctx) return 0;
+  zk_prof_drain(ctx);
+  std::string s;
+  char line[256];
+  for (auto& kv : ctx->prof_map) {
+    snprintf(line, sizeof(line), "%s %llu %.6f\n", kv.first.c_str(), (unsigned long long)kv.second.launches, kv.second.ms);
+    s += line;
+  }
+  if (buf && cap) {
+    size_t m = s.size() < cap - 1 ? s.size() : cap - 1;
+    memcpy(buf, s.data(), m);
+    buf[m] = 0;
+  }
+  return s.size() + 1;
+}
+
+}  // extern "C"

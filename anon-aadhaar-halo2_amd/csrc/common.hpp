@@ -1,0 +1,114 @@
+// Shared host-side plumbing of libamdzk: context, error capture, launch wrapper with optional
+// per-kernel HIP-event timing, and a growable device workspace.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/amdzk.h"
+#include "bn254.cuh"
+
+struct ProfEntry {
+  uint64_t launches = 0;
+  double ms = 0.0;
+};
+
+struct PendingEvt {
+  const char* name;
+  hipEvent_t a, b;
+};
+
+struct TwiddleKey {
+  uint32_t log_n;
+  uint64_t w[4];
+  bool operator<(const TwiddleKey& o) const {
+    if (log_n != o.log_n) return log_n < o.log_n;
+    for (int i = 0; i < 4; i++)
+      if (w[i] != o.w[i]) return w[i] < o.w[i];
+    return false;
+  }
+};
+
+struct amdzk_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int num_cu = 256;
+
+  // profiling
+  bool prof = false;
+  std::map<std::string, ProfEntry> prof_map;
+  std::vector<PendingEvt> pending;
+  std::vector<hipEvent_t> evt_pool;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+
+  // NTT twiddle tables: omega^i, i < max(1, n/2), resident per (log_n, omega)
+  std::map<TwiddleKey, bn254::Fr*> twiddles;
+
+  // workspaces (grow-only). ws[0]: NTT ping-pong; ws[1..]: MSM scratch.
+  struct Ws {
+    void* p = nullptr;
+    size_t cap = 0;
+  };
+  Ws ws[8];
+  // pinned host staging for small results
+  void* h_pinned = nullptr;
+  size_t h_pinned_cap = 0;
+};
+
+#define ZK_FAIL(ctx, code, ...)                         \
+  do {                                                  \
+    char _b[512];                                       \
+    snprintf(_b, sizeof(_b), __VA_ARGS__);              \
+    (ctx)->err = _b;                                    \
+    return (code);                                      \
+  } while (0)
+
+#define ZK_HIP(ctx, call)                                                                  \
+  do {                                                                                     \
+    hipError_t _e = (call);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      char _b[512];                                                                        \
+      snprintf(_b, sizeof(_b), "%s:%d %s -> %s", __FILE__, __LINE__, #call,                \
+               hipGetErrorString(_e));                                                     \
+      (ctx)->err = _b;                                                                     \
+      return AMDZK_E_HIP;                                                                  \
+    }                                                                                      \
+  } while (0)
+
+#define ZK_TRY(expr)            \
+  do {                          \
+    int _r = (expr);            \
+    if (_r != AMDZK_OK) return _r; \
+  } while (0)
+
+int zk_ws_reserve(amdzk_ctx* ctx, int slot, size_t bytes, void** out);
+int zk_pinned_reserve(amdzk_ctx* ctx, size_t bytes, void** out);
+hipEvent_t zk_evt_get(amdzk_ctx* ctx);
+void zk_prof_drain(amdzk_ctx* ctx);
+
+// Launch wrapper: kernel<<<grid, block, shmem, ctx->stream>>>(args...), optionally event-bracketed.
+#define ZK_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                        \
+  do {                                                                               \
+    hipEvent_t _ea = nullptr, _eb = nullptr;                                         \
+    if ((ctx)->prof) {                                                               \
+      _ea = zk_evt_get(ctx);                                                         \
+      _eb = zk_evt_get(ctx);                                                         \
+      (void)hipEventRecord(_ea, (ctx)->stream);                                          \
+    }                                                                                \
+    hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);      \
+    if ((ctx)->prof) {                                                               \
+      (void)hipEventRecord(_eb, (ctx)->stream);                                          \
+      (ctx)->pending.push_back(PendingEvt{name, _ea, _eb});                          \
+    }                                                                                \
+    ZK_HIP(ctx, hipGetLastError());                                                  \
+  } while (0)
+
+// entry points implemented in the kernel translation units
+int zk_ntt_dev(amdzk_ctx* ctx, bn254::Fr* d_a, uint32_t log_n, const uint64_t omega[4],
+               uint32_t flags, size_t ncols, size_t col_stride);

@@ -1,0 +1,513 @@
+// BN254 G1 multi-scalar multiplication for gfx950.
+//
+// Replaces halo2_proofs::arithmetic::best_multiexp as reached from
+// poly::kzg::commitment::ParamsKZG::{commit, commit_lagrange}
+// (halo2_proofs 0.2.0 @ v2023_01_20 [UP], /root/reference/Cargo.lock:469-471; SURVEY.md §8(a) a1,a2).
+//
+// The CPU original is Pippenger per thread-chunk: c = ceil(ln n) bit windows, 256/c+1 segments,
+// 2^c-1 buckets per segment, a running-sum fold per segment and c doublings between segments.
+// Same mathematics, different shape here, chosen for this chip:
+//
+//  * The bases of a ParamsKZG never change, and HBM is 288 GB: at upload time every base is expanded
+//    into its W window multiples T[w][i] = 2^(c*w) * g[i] (affine, 64 B). A scalar's W signed digits
+//    then all fall into ONE bucket set of 2^(c-1) buckets per column — no per-window bucket sets, no
+//    doublings, and the bucket fold runs once per column instead of once per window.
+//  * Bucket membership comes from a counting sort of (bucket, point-id) pairs (histogram -> scan ->
+//    scatter), so accumulation is gather-only and needs no locks.
+//  * Accumulation is cut into equal-sized tasks over the sorted list (not one thread per bucket):
+//    skewed witness columns (mostly 0/1/small limbs) and uniform scalars load the chip equally.
+//    Level 1 adds affine points into XYZZ accumulators (8M+2S per add), levels 2-3 fold the
+//    per-task partial sums.
+//  * The weighted fold sum_b (b+1)*B_b is done without a serial running sum: with b = r + 64*g,
+//    sum = sum_r r*C_r + sum_g (64g+1)*T_g where C_r / T_g are plain column / row sums, each a
+//    wavefront-wide (64-lane) shuffle-tree reduction.
+//  * Many columns over the same bases (all advice columns of a phase) go through every kernel in
+//    one launch: grid.y = column.
+//
+// No MFMA: this is 254-bit modular integer work (v_mad_u64_u32), and it is ALU-bound, not HBM-bound.
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.hpp"
+
+using namespace bn254;
+
+struct amdzk_srs {
+  uint32_t k = 0;
+  uint32_t c = 0;        // window bits
+  uint32_t W = 0;        // windows = ceil(255 / c)
+  size_t n = 0;
+  G1Affine* table[2] = {nullptr, nullptr};  // [basis] -> W x n affine points, window-major
+};
+
+namespace {
+
+constexpr int MSM_THREADS = 256;
+
+__device__ __forceinline__ uint4 ldg4(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+
+__device__ __forceinline__ Fq ld_fq(const Fq* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1];
+  Fq r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  return r;
+}
+__device__ __forceinline__ void st_fq(Fq* p, const Fq& v) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+__device__ __forceinline__ G1Affine ld_aff(const G1Affine* p) {
+  G1Affine r;
+  r.x = ld_fq(&p->x);
+  r.y = ld_fq(&p->y);
+  return r;
+}
+__device__ __forceinline__ void st_aff(G1Affine* p, const G1Affine& v) {
+  st_fq(&p->x, v.x);
+  st_fq(&p->y, v.y);
+}
+__device__ __forceinline__ G1X ld_x(const G1X* p) {
+  G1X r;
+  r.x = ld_fq(&p->x);
+  r.y = ld_fq(&p->y);
+  r.zz = ld_fq(&p->zz);
+  r.zzz = ld_fq(&p->zzz);
+  return r;
+}
+__device__ __forceinline__ void st_x(G1X* p, const G1X& v) {
+  st_fq(&p->x, v.x);
+  st_fq(&p->y, v.y);
+  st_fq(&p->zz, v.zz);
+  st_fq(&p->zzz, v.zzz);
+}
+
+// ------------------------------------------------------------------ window tables
+// next[i] = 2^c * prev[i], affine in, affine out (one Fermat inversion per point; upload-time only).
+__global__ void table_next_kernel(const G1Affine* prev, G1Affine* next, size_t n, uint32_t c) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  G1Affine p = ld_aff(prev + i);
+  G1X x = x_dbl_affine(p);
+  for (uint32_t k = 1; k < c; k++) x = x_dbl(x);
+  st_aff(next + i, x_to_affine(x));
+}
+
+// ------------------------------------------------------------------ digits
+// Signed base-2^C digits of the canonical scalar: d_w in [-(2^(C-1)-1), 2^(C-1)], sum d_w 2^(Cw) = s.
+// f(w, bucket, negative) is called for every non-zero digit; bucket = |d|-1.
+template <int C, class Fn>
+__device__ __forceinline__ void for_each_digit(const Fr& canon, Fn f) {
+  constexpr int W = (255 + C - 1) / C;
+  uint32_t carry = 0;
+#pragma unroll
+  for (int w = 0; w < W; w++) {
+    constexpr uint32_t mask = (1u << C) - 1u;
+    const int o = C * w, limb = o >> 5, sh = o & 31;
+    uint32_t v = 0;
+    if (limb < 8) {
+      v = canon.l[limb] >> sh;
+      if (sh + C > 32 && limb + 1 < 8) v |= canon.l[limb + 1] << (32 - sh);
+    }
+    v = (v & mask) + carry;
+    carry = v > (1u << (C - 1)) ? 1u : 0u;
+    uint32_t mag = carry ? ((1u << C) - v) : v;
+    if (mag != 0) f((uint32_t)w, mag - 1, carry);
+  }
+}
+
+struct DigitArgs {
+  const Fr* scalars;     // column 0
+  size_t col_stride;     // elements
+  uint32_t len;
+  uint32_t nb;           // buckets per column = 2^(C-1)
+  uint32_t* hist;        // [ncols][nb]
+  uint32_t* cursor;      // [ncols][nb]   (scatter only)
+  const uint32_t* off0;  // [ncols][nb+1] (scatter only)
+  uint32_t* entries;     // [ncols][ecap] (scatter only)
+  size_t ecap;
+  uint32_t table_n;      // row length of the window table (2^k)
+};
+
+template <int C, bool SCATTER>
+__global__ __launch_bounds__(MSM_THREADS) void msm_digit_kernel(DigitArgs a) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.len) return;
+  const uint32_t col = blockIdx.y;
+  const uint4* sp = reinterpret_cast<const uint4*>(a.scalars + (size_t)col * a.col_stride + i);
+  uint4 lo = sp[0], hi = sp[1];
+  if ((lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) == 0) return;
+  Fr s;
+  s.l[0] = lo.x; s.l[1] = lo.y; s.l[2] = lo.z; s.l[3] = lo.w;
+  s.l[4] = hi.x; s.l[5] = hi.y; s.l[6] = hi.z; s.l[7] = hi.w;
+  Fr canon = from_mont(s);  // = to_repr() of the original
+  uint32_t* hist = a.hist + (size_t)col * a.nb;
+  if (!SCATTER) {
+    for_each_digit<C>(canon, [&](uint32_t, uint32_t b, uint32_t) { atomicAdd(hist + b, 1u); });
+  } else {
+    uint32_t* cur = a.cursor + (size_t)col * a.nb;
+    const uint32_t* off = a.off0 + (size_t)col * (a.nb + 1);
+    uint32_t* ent = a.entries + (size_t)col * a.ecap;
+    for_each_digit<C>(canon, [&](uint32_t w, uint32_t b, uint32_t negv) {
+      uint32_t pos = off[b] + atomicAdd(cur + b, 1u);
+      ent[pos] = (w * a.table_n + i) | (negv << 31);
+    });
+  }
+}
+
+// ------------------------------------------------------------------ scan
+// off_out[b] = exclusive prefix sum over b of v[b]; off_out[nb] = total.
+//   src_is_hist: v[b] = src[b]                      (src has nb entries per column)
+//   else       : v[b] = ceil((src[b+1]-src[b]) / T)  (src has nb+1 entries per column)
+__global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* src, uint32_t* off_out,
+                                                         uint32_t nb, uint32_t T, int src_is_hist) {
+  __shared__ uint32_t part[1024];
+  const uint32_t col = blockIdx.x, t = threadIdx.x;
+  const uint32_t* s = src + (size_t)col * (src_is_hist ? nb : nb + 1);
+  uint32_t* o = off_out + (size_t)col * (nb + 1);
+  const uint32_t per = (nb + 1023) / 1024;
+  const uint32_t b0 = t * per, b1 = min(b0 + per, nb);
+  uint32_t sum = 0;
+  for (uint32_t b = b0; b < b1; b++) sum += src_is_hist ? s[b] : (s[b + 1] - s[b] + T - 1) / T;
+  part[t] = sum;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
+    uint32_t v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[t] - sum;
+  for (uint32_t b = b0; b < b1; b++) {
+    o[b] = run;
+    run += src_is_hist ? s[b] : (s[b + 1] - s[b] + T - 1) / T;
+  }
+  if (t == 1023) o[nb] = part[1023];
+}
+
+// ------------------------------------------------------------------ accumulation levels
+struct AccArgs {
+  const uint32_t* off_in;   // [ncols][nb+1] offsets of the input list per bucket
+  const uint32_t* off_out;  // [ncols][nb+1] task offsets per bucket (ceil(cnt/T))
+  uint32_t nb;
+  uint32_t T;
+  const uint32_t* entries;  // level 1 input
+  size_t ecap;
+  const G1Affine* table;
+  const G1X* in_list;       // level >= 2 input
+  size_t in_cap;
+  G1X* out_list;
+  size_t out_cap;
+};
+
+template <bool FIRST>
+__global__ __launch_bounds__(MSM_THREADS) void msm_accum_kernel(AccArgs a) {
+  const uint32_t col = blockIdx.y;
+  const uint32_t task = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t* off_in = a.off_in + (size_t)col * (a.nb + 1);
+  const uint32_t* off_out = a.off_out + (size_t)col * (a.nb + 1);
+  if (task >= off_out[a.nb]) return;
+  uint32_t lo = 0, hi = a.nb;  // largest b with off_out[b] <= task
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (off_out[mid] <= task) lo = mid; else hi = mid;
+  }
+  const uint32_t sub = task - off_out[lo];
+  const uint32_t start = off_in[lo] + sub * a.T;
+  const uint32_t end = min(start + a.T, off_in[lo + 1]);
+  G1X acc = G1X::inf();
+  if (FIRST) {
+    const uint32_t* ent = a.entries + (size_t)col * a.ecap;
+    for (uint32_t e = start; e < end; e++) {
+      uint32_t id = ent[e];
+      G1Affine p = ld_aff(a.table + (id & 0x7fffffffu));
+      if (id >> 31) p.y = neg(p.y);  // table points are never the identity unless the base is
+      acc = x_add_affine(acc, p);
+    }
+  } else {
+    const G1X* in = a.in_list + (size_t)col * a.in_cap;
+    for (uint32_t e = start; e < end; e++) acc = x_add(acc, ld_x(in + e));
+  }
+  st_x(a.out_list + (size_t)col * a.out_cap + task, acc);
+}
+
+// Final level: one thread per bucket folds whatever is left and writes the dense bucket array.
+__global__ __launch_bounds__(MSM_THREADS) void msm_accum_final_kernel(const uint32_t* off_in_all,
+                                                                       uint32_t nb, const G1X* in_list,
+                                                                       size_t in_cap, G1X* dense) {
+  const uint32_t col = blockIdx.y;
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  const uint32_t* off_in = off_in_all + (size_t)col * (nb + 1);
+  const G1X* in = in_list + (size_t)col * in_cap;
+  G1X acc = G1X::inf();
+  for (uint32_t e = off_in[b]; e < off_in[b + 1]; e++) acc = x_add(acc, ld_x(in + e));
+  st_x(dense + (size_t)col * nb + b, acc);
+}
+
+// ------------------------------------------------------------------ wavefront reductions
+__device__ __forceinline__ Fq shfl_xor_fq(const Fq& v, int m) {
+  Fq r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.l[i] = __shfl_xor(v.l[i], m, 64);
+  return r;
+}
+__device__ __forceinline__ G1X shfl_xor_x(const G1X& v, int m) {
+  G1X r;
+  r.x = shfl_xor_fq(v.x, m);
+  r.y = shfl_xor_fq(v.y, m);
+  r.zz = shfl_xor_fq(v.zz, m);
+  r.zzz = shfl_xor_fq(v.zzz, m);
+  return r;
+}
+// All 64 lanes end with the sum of the 64 inputs.
+__device__ __forceinline__ G1X wave_sum(G1X v) {
+#pragma unroll 1
+  for (int m = 32; m >= 1; m >>= 1) v = x_add(v, shfl_xor_x(v, m));
+  return v;
+}
+
+// rows[col][g] = sum_r dense[col][64g + r]   (one wave per g)
+// cols[col][r] = sum_g dense[col][64g + r]   (one wave per r)
+__global__ __launch_bounds__(64) void msm_rowcol_kernel(const G1X* dense, uint32_t nb, G1X* rows,
+                                                         G1X* cols) {
+  const uint32_t col = blockIdx.y, lane = threadIdx.x;
+  const uint32_t G = nb >> 6;
+  const G1X* d = dense + (size_t)col * nb;
+  if (blockIdx.x < G) {
+    const uint32_t g = blockIdx.x;
+    G1X s = wave_sum(ld_x(d + 64 * g + lane));
+    if (lane == 0) st_x(rows + (size_t)col * G + g, s);
+  } else {
+    const uint32_t r = blockIdx.x - G;
+    G1X acc = G1X::inf();
+    for (uint32_t g = lane; g < G; g += 64) acc = x_add(acc, ld_x(d + 64 * g + r));
+    G1X s = wave_sum(acc);
+    if (lane == 0) st_x(cols + (size_t)col * 64 + r, s);
+  }
+}
+
+__device__ __forceinline__ G1X x_mul_small(const G1X& p, uint32_t k) {
+  G1X acc = G1X::inf();
+#pragma unroll 1
+  for (int b = 15; b >= 0; b--) {
+    acc = x_dbl(acc);
+    if ((k >> b) & 1) acc = x_add(acc, p);
+  }
+  return acc;
+}
+
+// out[col] = sum_r r*cols[r] + sum_g (64g+1)*rows[g]
+__global__ __launch_bounds__(512) void msm_fold_kernel(const G1X* rows, const G1X* cols, uint32_t nb,
+                                                        G1X* out) {
+  __shared__ G1X part[9];
+  const uint32_t col = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const uint32_t G = nb >> 6;
+  G1X v = G1X::inf();
+  if (t < G) v = x_mul_small(ld_x(rows + (size_t)col * G + t), 64 * t + 1);
+  G1X s = wave_sum(v);
+  if (lane == 0) part[wv] = s;
+  if (wv == 0) {
+    G1X c = x_mul_small(ld_x(cols + (size_t)col * 64 + lane), lane);
+    G1X cs = wave_sum(c);
+    if (lane == 0) part[8] = cs;
+  }
+  __syncthreads();
+  if (t == 0) {
+    G1X acc = part[8];
+    const uint32_t nw = blockDim.x >> 6;
+    for (uint32_t i = 0; i < nw; i++) acc = x_add(acc, part[i]);
+    st_x(out + col, acc);
+  }
+}
+
+uint32_t pick_window_bits(uint32_t k) {
+  const char* e = getenv("AMDZK_MSM_C");
+  if (e) {
+    int v = atoi(e);
+    if (v >= 8 && v <= 16) return (uint32_t)v;
+  }
+  if (k <= 10) return 8;
+  if (k <= 12) return 10;
+  if (k <= 13) return 11;
+  if (k <= 14) return 12;
+  if (k <= 16) return 13;
+  if (k <= 18) return 14;
+  if (k <= 20) return 15;
+  return 16;
+}
+
+template <bool SCATTER>
+int launch_digits(amdzk_ctx* ctx, uint32_t c, const DigitArgs& a, dim3 grid) {
+  dim3 block(MSM_THREADS);
+  const char* nm = SCATTER ? "msm_scatter" : "msm_hist";
+  switch (c) {
+#define ZK_CASE(CC)                                                \
+  case CC: {                                                       \
+    auto kfn = msm_digit_kernel<CC, SCATTER>;                      \
+    ZK_LAUNCH(ctx, nm, kfn, grid, block, 0, a);                    \
+  } break;
+    ZK_CASE(8) ZK_CASE(9) ZK_CASE(10) ZK_CASE(11) ZK_CASE(12) ZK_CASE(13) ZK_CASE(14) ZK_CASE(15) ZK_CASE(16)
+#undef ZK_CASE
+    default:
+      ZK_FAIL(ctx, AMDZK_E_INVALID, "msm: window bits %u unsupported", c);
+  }
+  return AMDZK_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------- host side
+int zk_srs_upload(amdzk_ctx* ctx, const uint64_t* g, const uint64_t* g_lagrange, uint32_t k,
+                  amdzk_srs** out) {
+  if (!out || (!g && !g_lagrange)) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_upload: null argument");
+  if (k > 26) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "srs_upload: k %u > 26", k);
+  amdzk_srs* s = new amdzk_srs();
+  s->k = k;
+  s->n = (size_t)1 << k;
+  s->c = pick_window_bits(k);
+  s->W = (255 + s->c - 1) / s->c;
+  const uint64_t* src[2] = {g, g_lagrange};
+  for (int b = 0; b < 2; b++) {
+    if (!src[b]) continue;
+    size_t bytes = (size_t)s->W * s->n * sizeof(G1Affine);
+    hipError_t e = hipMalloc((void**)&s->table[b], bytes);
+    if (e != hipSuccess) {
+      for (int j = 0; j < 2; j++)
+        if (s->table[j]) hipFree(s->table[j]);
+      delete s;
+      ZK_FAIL(ctx, AMDZK_E_NOMEM, "srs_upload: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
+    ZK_HIP(ctx, hipMemcpyAsync(s->table[b], src[b], s->n * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream));
+    dim3 grid((unsigned)((s->n + 255) / 256)), block(256);
+    for (uint32_t w = 1; w < s->W; w++)
+      ZK_LAUNCH(ctx, "msm_table_next", table_next_kernel, grid, block, 0, s->table[b] + (size_t)(w - 1) * s->n,
+                s->table[b] + (size_t)w * s->n, s->n, s->c);
+  }
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host source buffers may be released by the caller
+  *out = s;
+  return AMDZK_OK;
+}
+
+void zk_srs_free(amdzk_ctx*, amdzk_srs* s) {
+  if (!s) return;
+  for (int b = 0; b < 2; b++)
+    if (s->table[b]) hipFree(s->table[b]);
+  delete s;
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ncols MSMs of length len over srs->table[basis]; results (XYZZ) land in d_out[ncols].
+int zk_msm_dev_xyzz(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const Fr* d_scalars, size_t ncols,
+                    size_t len, size_t col_stride, G1X** d_out) {
+  if (!srs || basis < 0 || basis > 1 || !srs->table[basis]) ZK_FAIL(ctx, AMDZK_E_INVALID, "msm: basis %d not uploaded", basis);
+  if (len > srs->n) ZK_FAIL(ctx, AMDZK_E_INVALID, "msm: len %zu > 2^k = %zu", len, srs->n);
+  if (ncols == 0 || ncols > 65535) ZK_FAIL(ctx, AMDZK_E_INVALID, "msm: ncols %zu out of range", ncols);
+  const uint32_t c = srs->c, W = srs->W, nb = 1u << (c - 1);
+  const size_t ecap = align_up(len * W ? len * W : 1, 4);
+  if ((uint64_t)W * srs->n >= (1ull << 31)) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "msm: table too large for 31-bit ids");
+
+  // task sizes
+  const size_t e_total = ecap * ncols;
+  uint32_t T1 = 4;
+  while (T1 < 64 && e_total / T1 > 262144) T1 <<= 1;
+  if (const char* e = getenv("AMDZK_MSM_T1")) T1 = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : T1;
+  const uint32_t T2 = 8;
+  const size_t cap1 = ecap / T1 + nb + 1;
+  const size_t cap2 = cap1 / T2 + nb + 1;
+
+  // workspace layout (slot 1): hist | cursor | off0 | off1 | off2 | entries | list1 | list2 | dense | rows | cols | out
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+  const size_t o_hist = take(ncols * nb * 4), o_cur = take(ncols * nb * 4);
+  const size_t o_off0 = take(ncols * (nb + 1) * 4), o_off1 = take(ncols * (nb + 1) * 4), o_off2 = take(ncols * (nb + 1) * 4);
+  const size_t o_ent = take(ncols * ecap * 4);
+  const size_t o_l1 = take(ncols * cap1 * sizeof(G1X)), o_l2 = take(ncols * cap2 * sizeof(G1X));
+  const size_t o_dense = take(ncols * nb * sizeof(G1X));
+  const size_t G = nb >> 6;
+  const size_t o_rows = take(ncols * G * sizeof(G1X)), o_cols = take(ncols * 64 * sizeof(G1X));
+  const size_t o_out = take(ncols * sizeof(G1X));
+  char* ws = nullptr;
+  ZK_TRY(zk_ws_reserve(ctx, 1, o, (void**)&ws));
+  uint32_t* hist = (uint32_t*)(ws + o_hist);
+  uint32_t* cursor = (uint32_t*)(ws + o_cur);
+  uint32_t *off0 = (uint32_t*)(ws + o_off0), *off1 = (uint32_t*)(ws + o_off1), *off2 = (uint32_t*)(ws + o_off2);
+  uint32_t* entries = (uint32_t*)(ws + o_ent);
+  G1X *l1 = (G1X*)(ws + o_l1), *l2 = (G1X*)(ws + o_l2), *dense = (G1X*)(ws + o_dense);
+  G1X *rows = (G1X*)(ws + o_rows), *cols = (G1X*)(ws + o_cols), *outp = (G1X*)(ws + o_out);
+
+  // hist and cursor are adjacent: one memset
+  ZK_HIP(ctx, hipMemsetAsync(hist, 0, (o_off0 - o_hist), ctx->stream));
+
+  DigitArgs da;
+  da.scalars = d_scalars;
+  da.col_stride = col_stride;
+  da.len = (uint32_t)len;
+  da.nb = nb;
+  da.hist = hist;
+  da.cursor = cursor;
+  da.off0 = off0;
+  da.entries = entries;
+  da.ecap = ecap;
+  da.table_n = (uint32_t)srs->n;
+  dim3 dgrid((unsigned)((len + MSM_THREADS - 1) / MSM_THREADS), (unsigned)ncols);
+  if (len > 0) ZK_TRY(launch_digits<false>(ctx, c, da, dgrid));
+  ZK_LAUNCH(ctx, "msm_scan", msm_scan_kernel, dim3((unsigned)ncols), dim3(1024), 0, hist, off0, nb, 1u, 1);
+  if (len > 0) ZK_TRY(launch_digits<true>(ctx, c, da, dgrid));
+  ZK_LAUNCH(ctx, "msm_scan", msm_scan_kernel, dim3((unsigned)ncols), dim3(1024), 0, off0, off1, nb, T1, 0);
+  ZK_LAUNCH(ctx, "msm_scan", msm_scan_kernel, dim3((unsigned)ncols), dim3(1024), 0, off1, off2, nb, T2, 0);
+
+  AccArgs a1;
+  a1.off_in = off0; a1.off_out = off1; a1.nb = nb; a1.T = T1;
+  a1.entries = entries; a1.ecap = ecap; a1.table = srs->table[basis];
+  a1.in_list = nullptr; a1.in_cap = 0; a1.out_list = l1; a1.out_cap = cap1;
+  ZK_LAUNCH(ctx, "msm_accum_l1", msm_accum_kernel<true>, dim3((unsigned)((cap1 + MSM_THREADS - 1) / MSM_THREADS), (unsigned)ncols),
+            dim3(MSM_THREADS), 0, a1);
+  AccArgs a2 = a1;
+  a2.off_in = off1; a2.off_out = off2; a2.T = T2; a2.entries = nullptr; a2.table = nullptr;
+  a2.in_list = l1; a2.in_cap = cap1; a2.out_list = l2; a2.out_cap = cap2;
+  ZK_LAUNCH(ctx, "msm_accum_l2", msm_accum_kernel<false>, dim3((unsigned)((cap2 + MSM_THREADS - 1) / MSM_THREADS), (unsigned)ncols),
+            dim3(MSM_THREADS), 0, a2);
+  ZK_LAUNCH(ctx, "msm_accum_final", msm_accum_final_kernel, dim3((nb + MSM_THREADS - 1) / MSM_THREADS, (unsigned)ncols),
+            dim3(MSM_THREADS), 0, off2, nb, l2, cap2, dense);
+  ZK_LAUNCH(ctx, "msm_rowcol", msm_rowcol_kernel, dim3((unsigned)(G + 64), (unsigned)ncols), dim3(64), 0, dense, nb, rows, cols);
+  const unsigned fold_threads = G > 64 ? (unsigned)G : 64u;
+  ZK_LAUNCH(ctx, "msm_fold", msm_fold_kernel, dim3((unsigned)ncols), dim3(fold_threads), 0, rows, cols, nb, outp);
+  *d_out = outp;
+  return AMDZK_OK;
+}
+
+// Host finish: XYZZ -> normalised Jacobian (z = 1) with one shared inversion (Montgomery's trick).
+int zk_msm_finish(amdzk_ctx* ctx, const G1X* d_res, size_t ncols, uint64_t* out_jac) {
+  G1X* h = nullptr;
+  ZK_TRY(zk_pinned_reserve(ctx, ncols * sizeof(G1X), (void**)&h));
+  ZK_HIP(ctx, hipMemcpyAsync(h, d_res, ncols * sizeof(G1X), hipMemcpyDeviceToHost, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<Fq> pre(ncols);
+  Fq acc = Fq::one();
+  for (size_t i = 0; i < ncols; i++) {
+    pre[i] = acc;
+    if (!h[i].is_inf()) acc = mul(acc, h[i].zzz);
+  }
+  acc = inv(acc);
+  for (size_t i = ncols; i-- > 0;) {
+    G1Jac* o = reinterpret_cast<G1Jac*>(out_jac + 12 * i);
+    if (h[i].is_inf()) {
+      o->x = Fq::zero();
+      o->y = Fq::one();
+      o->z = Fq::zero();
+      continue;
+    }
+    Fq izzz = mul(acc, pre[i]);
+    acc = mul(acc, h[i].zzz);
+    Fq iz = mul(h[i].zz, izzz);
+    Fq izz = sqr(iz);
+    o->x = mul(h[i].x, izz);
+    o->y = mul(h[i].y, izzz);
+    o->z = Fq::one();
+  }
+  return AMDZK_OK;
+}

@@ -1,0 +1,358 @@
+// Fr number-theoretic transform for gfx950.
+//
+// Replaces halo2_proofs::arithmetic::best_fft (and, through the coset/scale options, the NTT
+// inside poly::domain::EvaluationDomain::{lagrange_to_coeff, coeff_to_lagrange, coeff_to_extended,
+// extended_to_coeff}) — halo2_proofs 0.2.0 @ v2023_01_20 [UP], /root/reference/Cargo.lock:469-471;
+// SURVEY.md §8(a) rows a3-a6.
+//
+// The CPU original is a bit-reversal followed by log_n radix-2 rounds over the whole array (log_n
+// passes over memory). Here the transform is a 1-, 2- or 3-step Cooley-Tukey decomposition
+//     n = n1*n2*n3,  input index i = (i1,i2,i3) row-major, output index j = j1 + n1*j2 + n1*n2*j3
+// in which step p does all length-n_p sub-transforms of one digit inside LDS (radix-2 DIF rounds on a
+// tile of n_p x C elements; C consecutive elements of the faster digits share the tile so that
+// every global access is a run of C*32 contiguous bytes), multiplies by the inter-step twiddle
+// omega^(g*i_{p+1}*J_p) on the way out, and the last step writes straight to natural order. The
+// vector therefore crosses HBM once per step (2-3 times), not log_n times, and no bit-reversal pass
+// exists. Arithmetic is exact, so the result is bit-identical to best_fft's.
+//
+// Data stay AoS (32-byte Fr, two 16-byte accesses per lane) — the host format — so Rust slices and
+// device columns share one layout.
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.hpp"
+
+using namespace bn254;
+
+namespace {
+
+constexpr int NTT_THREADS = 256;
+
+struct NttPassArgs {
+  const Fr* in;
+  Fr* out;
+  size_t in_col_stride;   // elements between consecutive columns (batch)
+  size_t out_col_stride;
+  const Fr* tw;           // omega^i, i < n/2
+  uint32_t log_n;
+  uint32_t s;             // log2 of this step's sub-transform length n_p
+  uint32_t log_c;         // log2 of C (tile = 2^s x C elements)
+  uint32_t log_stride;    // log2 of S_p = product of later radices (0 in the last step)
+  uint32_t log_prev;      // log2 of N_{p-1} = product of earlier radices
+  uint32_t log_n1;        // log2 of n1
+  uint32_t log_n2;        // log2 of n2 (3-step only)
+  uint32_t log_next;      // log2 of n_{p+1} (non-last steps)
+  uint32_t pass;          // 0-based step index
+  uint32_t npass;
+  uint32_t in_len;        // first step: elements at index >= in_len read as zero (zero padding)
+  uint32_t flags;
+  Fr in_c[2];             // first step, IN_COSET: element i is multiplied by in_c[i%3 - 1] when i%3 != 0
+  Fr out_c[3];            // last step, OUT_MUL: element j is multiplied by out_c[j%3]
+};
+
+constexpr uint32_t F_IN_COSET = 1u;
+constexpr uint32_t F_OUT_MUL = 2u;
+
+__device__ __forceinline__ uint32_t brev(uint32_t x, uint32_t bits) {
+  return bits == 0 ? 0u : (__brev(x) >> (32 - bits));
+}
+
+__device__ __forceinline__ Fr ld_fr(const Fr* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1];
+  Fr r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  return r;
+}
+__device__ __forceinline__ void st_fr(Fr* p, const Fr& v) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+// omega^e for e in [0, n): table holds the first half, the second half is its negation.
+__device__ __forceinline__ Fr tw_lookup(const Fr* tw, uint32_t e, uint32_t log_n) {
+  uint32_t half = 1u << (log_n - 1);
+  Fr w = ld_fr(tw + (e & (half - 1)));
+  return (e & half) ? neg(w) : w;
+}
+
+template <bool LAST>
+__global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
+  extern __shared__ uint4 lds_raw[];
+  Fr* L = reinterpret_cast<Fr*>(lds_raw);
+  const uint32_t tid = threadIdx.x;
+  const uint32_t C = 1u << a.log_c;
+  const uint32_t rows = 1u << a.s;
+  const uint32_t tile = rows << a.log_c;
+  Fr* TW = L + tile;  // rows/2 sub-transform twiddles omega_{n_p}^i
+  const uint32_t tile_id = blockIdx.x;
+  const Fr* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
+  Fr* out = a.out + (size_t)blockIdx.y * a.out_col_stride;
+  const uint32_t log_n = a.log_n;
+
+  // ---- stage the sub-transform twiddles: omega_{n_p}^i = omega^(i * n/n_p)
+  for (uint32_t i = tid; i < (rows >> 1); i += NTT_THREADS) TW[i] = ld_fr(a.tw + ((size_t)i << (log_n - a.s)));
+
+  // ---- load the tile
+  size_t in_base, row_stride;
+  uint32_t hi = 0, lo_base = 0, j2 = 0, j1_blk = 0;
+  if (!LAST) {
+    const uint32_t log_lo_blocks = a.log_stride - a.log_c;
+    hi = tile_id >> log_lo_blocks;
+    lo_base = (tile_id & ((1u << log_lo_blocks) - 1)) << a.log_c;
+    in_base = ((size_t)hi << (a.s + a.log_stride)) + lo_base;
+    row_stride = (size_t)1 << a.log_stride;
+    // element (x, c) at in_base + x*row_stride + c ; 16-byte pieces, c fastest
+    const uint32_t pieces = tile * 2, ppr = C * 2;
+    for (uint32_t q = tid; q < pieces; q += NTT_THREADS) {
+      uint32_t x = q / ppr, c2 = q % ppr;
+      size_t gi = in_base + (size_t)x * row_stride + (c2 >> 1);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (a.pass != 0 || gi < a.in_len) v = reinterpret_cast<const uint4*>(in + gi)[c2 & 1];
+      lds_raw[q] = v;
+    }
+  } else {
+    // rows of the tile are C consecutive values of j1 (the fastest output digit)
+    if (a.npass == 3) {
+      j2 = tile_id & ((1u << a.log_n2) - 1);
+      j1_blk = tile_id >> a.log_n2;
+    } else {
+      j1_blk = tile_id;
+    }
+    row_stride = a.npass == 1 ? 0 : ((size_t)1 << (log_n - a.log_n1));
+    in_base = (size_t)(j1_blk << a.log_c) * row_stride + (a.npass == 3 ? ((size_t)j2 << a.s) : 0);
+    const uint32_t pieces = tile * 2, ppr = rows * 2;
+    for (uint32_t q = tid; q < pieces; q += NTT_THREADS) {
+      uint32_t rr = q / ppr, x2 = q % ppr;
+      size_t gi = in_base + (size_t)rr * row_stride + (x2 >> 1);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (a.pass != 0 || gi < a.in_len) v = reinterpret_cast<const uint4*>(in + gi)[x2 & 1];
+      lds_raw[((((x2 >> 1) << a.log_c) + rr) << 1) + (x2 & 1)] = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- first step only: move into the coset (distribute_powers_zeta) — whole elements
+  if (a.pass == 0 && (a.flags & F_IN_COSET)) {
+    for (uint32_t e = tid; e < tile; e += NTT_THREADS) {
+      uint32_t x = e >> a.log_c, c = e & (C - 1);
+      size_t gi = LAST ? (in_base + (size_t)c * row_stride + x) : (in_base + (size_t)x * row_stride + c);
+      uint32_t m = (uint32_t)(gi % 3);
+      if (m != 0 && gi < a.in_len) L[e] = mul(L[e], a.in_c[m - 1]);
+    }
+    __syncthreads();
+  }
+
+  // ---- radix-2 DIF rounds over the row dimension; result row r holds output index brev(r)
+  for (int st = (int)a.s - 1; st >= 0; --st) {
+    const uint32_t h = 1u << st;
+    for (uint32_t b = tid; b < (tile >> 1); b += NTT_THREADS) {
+      uint32_t c = b & (C - 1), m = b >> a.log_c;
+      uint32_t i = m & (h - 1), blk = m >> st;
+      uint32_t x0 = (blk << (st + 1)) + i;
+      uint32_t e0 = (x0 << a.log_c) + c, e1 = ((x0 + h) << a.log_c) + c;
+      Fr u = L[e0], v = L[e1];
+      L[e0] = add(u, v);
+      Fr d = sub(u, v);
+      if (st > 0) d = mul(d, TW[i << (a.s - 1 - st)]);
+      L[e1] = d;
+    }
+    __syncthreads();
+  }
+
+  // ---- store
+  if (!LAST) {
+    // twiddle omega^(g * i_next * (J_prev + N_prev*j)),  g = n / N_{p+1}
+    const uint32_t J_prev = hi;  // step 0: hi = 0; step 1 of 3: hi = j1
+    const uint32_t log_g = log_n - (a.log_prev + a.s + a.log_next);
+    const uint32_t sh_next = a.log_stride - a.log_next;
+    for (uint32_t e = tid; e < tile; e += NTT_THREADS) {
+      uint32_t j = e >> a.log_c, c = e & (C - 1);
+      Fr x = L[(brev(j, a.s) << a.log_c) + c];
+      uint32_t i_next = (lo_base + c) >> sh_next;
+      uint32_t Jp = J_prev + (j << a.log_prev);
+      uint32_t ex = (i_next * Jp) << log_g;
+      if (ex != 0) x = mul(x, tw_lookup(a.tw, ex, log_n));
+      st_fr(out + in_base + (size_t)j * row_stride + c, x);
+    }
+  } else {
+    const size_t out_base = (size_t)(j1_blk << a.log_c) + (a.npass == 3 ? ((size_t)j2 << a.log_n1) : 0);
+    const uint32_t log_ostride = log_n - a.s;  // N_{P-1}
+    for (uint32_t e = tid; e < tile; e += NTT_THREADS) {
+      uint32_t j = e >> a.log_c, rr = e & (C - 1);
+      Fr x = L[(brev(j, a.s) << a.log_c) + rr];
+      size_t oi = out_base + rr + ((size_t)j << log_ostride);
+      if (a.flags & F_OUT_MUL) x = mul(x, a.out_c[oi % 3]);
+      st_fr(out + oi, x);
+    }
+  }
+}
+
+// tw[i] = omega^i for i < count. Each thread raises omega to its chunk start, then walks.
+__global__ void twiddle_gen_kernel(Fr* tw, Fr omega, uint32_t count, uint32_t chunk) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t start = (uint64_t)t * chunk;
+  if (start >= count) return;
+  Fr cur = pow_u64(omega, start);
+  uint32_t end = (uint32_t)((start + chunk < count) ? start + chunk : count);
+  for (uint32_t i = (uint32_t)start; i < end; i++) {
+    st_fr(tw + i, cur);
+    cur = mul(cur, omega);
+  }
+}
+
+__global__ void copy_cols_kernel(const uint4* src, uint4* dst, size_t n16, size_t src_stride16,
+                                 size_t dst_stride16) {
+  const uint4* s = src + (size_t)blockIdx.y * src_stride16;
+  uint4* d = dst + (size_t)blockIdx.y * dst_stride16;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+    d[i] = s[i];
+}
+
+int get_twiddles(amdzk_ctx* ctx, uint32_t log_n, const uint64_t omega[4], Fr** out) {
+  TwiddleKey key;
+  key.log_n = log_n;
+  for (int i = 0; i < 4; i++) key.w[i] = omega[i];
+  auto it = ctx->twiddles.find(key);
+  if (it != ctx->twiddles.end()) {
+    *out = it->second;
+    return AMDZK_OK;
+  }
+  uint32_t count = log_n == 0 ? 1 : (1u << (log_n - 1));
+  Fr* d = nullptr;
+  ZK_HIP(ctx, hipMalloc((void**)&d, (size_t)count * sizeof(Fr)));
+  Fr w;
+  memcpy(w.l, omega, 32);
+  uint32_t chunk = 64;
+  uint32_t threads = (count + chunk - 1) / chunk;
+  dim3 grid((threads + 63) / 64), block(64);
+  ZK_LAUNCH(ctx, "twiddle_gen", twiddle_gen_kernel, grid, block, 0, d, w, count, chunk);
+  ctx->twiddles[key] = d;
+  *out = d;
+  return AMDZK_OK;
+}
+
+// Plan: number of steps and their radices.
+struct Plan {
+  uint32_t npass;
+  uint32_t s[3];
+};
+
+uint32_t env_u32(const char* name, uint32_t dflt) {
+  const char* v = getenv(name);
+  return v ? (uint32_t)atoi(v) : dflt;
+}
+
+Plan make_plan(uint32_t log_n, uint32_t tile_log) {
+  // Keep at least 4 elements (128 contiguous bytes) per global run: s <= tile_log - 2.
+  uint32_t smax = tile_log - 2;
+  Plan p;
+  if (log_n <= tile_log) {  // whole column in one tile
+    p.npass = 1;
+    p.s[0] = log_n;
+    p.s[1] = p.s[2] = 0;
+    return p;
+  }
+  p.npass = log_n <= 2 * smax ? 2 : 3;
+  uint32_t rem = log_n;
+  for (uint32_t i = 0; i < p.npass; i++) {
+    uint32_t left = p.npass - i;
+    p.s[i] = (rem + left - 1) / left;
+    rem -= p.s[i];
+  }
+  for (uint32_t i = p.npass; i < 3; i++) p.s[i] = 0;
+  return p;
+}
+
+}  // namespace
+
+// Generalised entry used by the C ABI and by the domain helpers.
+//   in_len   : number of valid input elements per column (rest read as zero); 0 means n.
+//   in_coset : if non-null, 2 constants applied to input element i with i%3 = 1, 2
+//   out_mul  : if non-null, 3 constants applied to output element j by j%3
+int zk_ntt_ex(amdzk_ctx* ctx, Fr* d_a, uint32_t log_n, const uint64_t omega[4], size_t ncols,
+              size_t col_stride, uint32_t in_len, const Fr* in_coset, const Fr* out_mul) {
+  if (log_n > 27) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "ntt: log_n %u > 27", log_n);
+  if (ncols == 0) return AMDZK_OK;
+  const size_t n = (size_t)1 << log_n;
+  if (ncols > 1 && col_stride < n) ZK_FAIL(ctx, AMDZK_E_INVALID, "ntt: col_stride < n");
+  if (ncols > 65535) ZK_FAIL(ctx, AMDZK_E_INVALID, "ntt: more than 65535 columns in one call");
+  Fr* tw = nullptr;
+  ZK_TRY(get_twiddles(ctx, log_n, omega, &tw));
+  const uint32_t tile_log = env_u32("AMDZK_NTT_TILE_LOG", 10);
+  Plan plan = make_plan(log_n, tile_log);
+
+  Fr* ws = nullptr;
+  ZK_TRY(zk_ws_reserve(ctx, 0, ncols * n * sizeof(Fr), (void**)&ws));
+
+  NttPassArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tw = tw;
+  a.log_n = log_n;
+  a.npass = plan.npass;
+  a.log_n1 = plan.s[0];
+  a.log_n2 = plan.s[1];
+  a.in_len = in_len ? in_len : (uint32_t)n;
+  if (in_coset) {
+    a.in_c[0] = in_coset[0];
+    a.in_c[1] = in_coset[1];
+  }
+  if (out_mul) {
+    a.out_c[0] = out_mul[0];
+    a.out_c[1] = out_mul[1];
+    a.out_c[2] = out_mul[2];
+  }
+  uint32_t log_prev = 0;
+  for (uint32_t p = 0; p < plan.npass; p++) {
+    const bool last = (p + 1 == plan.npass);
+    a.pass = p;
+    a.s = plan.s[p];
+    a.log_prev = log_prev;
+    a.log_stride = log_n - log_prev - a.s;
+    a.log_next = last ? 0 : plan.s[p + 1];
+    uint32_t lc = a.s >= tile_log ? 0 : tile_log - a.s;
+    if (!last && lc > a.log_stride) lc = a.log_stride;
+    if (last) {
+      if (plan.npass == 1) lc = 0;
+      else if (lc > a.log_n1) lc = a.log_n1;
+    }
+    a.log_c = lc;
+    a.flags = 0;
+    if (p == 0 && in_coset) a.flags |= F_IN_COSET;
+    if (last && out_mul) a.flags |= F_OUT_MUL;
+    // buffers: first step reads the caller's column, last step writes it; in between the workspace.
+    bool in_is_user = (p == 0);
+    bool out_is_user = last && plan.npass > 1;
+    a.in = in_is_user ? d_a : ws;
+    a.in_col_stride = in_is_user ? col_stride : n;
+    a.out = out_is_user ? d_a : ws;
+    a.out_col_stride = out_is_user ? col_stride : n;
+    if (plan.npass == 1) {  // single tile per column: in place is safe (all loads precede all stores)
+      a.out = d_a;
+      a.out_col_stride = col_stride;
+    }
+    const uint32_t tile_elems_log = a.s + a.log_c;
+    dim3 grid((uint32_t)(n >> tile_elems_log), (uint32_t)ncols), block(NTT_THREADS);
+    size_t shmem = (((size_t)1 << tile_elems_log) + ((size_t)1 << a.s) / 2 + 1) * sizeof(Fr);
+    if (last)
+      ZK_LAUNCH(ctx, "ntt_step_last", ntt_step_kernel<true>, grid, block, shmem, a);
+    else
+      ZK_LAUNCH(ctx, "ntt_step", ntt_step_kernel<false>, grid, block, shmem, a);
+    log_prev += a.s;
+  }
+  return AMDZK_OK;
+}
+
+int zk_ntt_dev(amdzk_ctx* ctx, Fr* d_a, uint32_t log_n, const uint64_t omega[4], uint32_t flags,
+               size_t ncols, size_t col_stride) {
+  if (flags & AMDZK_NTT_SCALE_NINV) {
+    // 1/n as a Montgomery constant: (2^log_n)^-1
+    Fr two = add(Fr::one(), Fr::one());
+    Fr ninv = inv(pow_u64(two, log_n));
+    Fr oc[3] = {ninv, ninv, ninv};
+    return zk_ntt_ex(ctx, d_a, log_n, omega, ncols, col_stride, 0, nullptr, oc);
+  }
+  return zk_ntt_ex(ctx, d_a, log_n, omega, ncols, col_stride, 0, nullptr, nullptr);
+}

@@ -1,0 +1,162 @@
+"""ctypes binding of include/amdzk.h. One `Context` = one amdzk_ctx (one GPU, one host thread)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class AmdzkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("amdzk error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(_HERE, "libamdzk.so")
+
+
+def lib():
+    """Load libamdzk.so (built in-tree by __graft_entry__.build()). Fails loudly if missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = lib_path()
+    if not os.path.exists(p):
+        raise AmdzkError(-1, "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % p)
+    L = C.CDLL(p)
+    vp, sz, u32, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int
+    sig = {
+        "amdzk_version": (i32, []),
+        "amdzk_init": (i32, [i32, C.POINTER(vp)]),
+        "amdzk_destroy": (None, [vp]),
+        "amdzk_last_error": (C.c_char_p, [vp]),
+        "amdzk_set_stream": (i32, [vp, vp]),
+        "amdzk_sync": (i32, [vp]),
+        "amdzk_dev_alloc": (i32, [vp, sz, C.POINTER(vp)]),
+        "amdzk_dev_free": (i32, [vp, vp]),
+        "amdzk_dev_upload": (i32, [vp, vp, vp, sz]),
+        "amdzk_dev_download": (i32, [vp, vp, vp, sz]),
+        "amdzk_dev_memset": (i32, [vp, vp, i32, sz]),
+        "amdzk_srs_upload": (i32, [vp, vp, vp, u32, C.POINTER(vp)]),
+        "amdzk_srs_free": (None, [vp, vp]),
+        "amdzk_msm_g1": (i32, [vp, vp, i32, vp, sz, vp]),
+        "amdzk_msm_g1_batch": (i32, [vp, vp, i32, C.POINTER(vp), sz, sz, vp]),
+        "amdzk_msm_g1_dev": (i32, [vp, vp, i32, vp, sz, sz, sz, vp]),
+        "amdzk_ntt_fr": (i32, [vp, vp, u32, vp, u32]),
+        "amdzk_ntt_fr_dev": (i32, [vp, vp, u32, vp, u32, sz, sz]),
+        "amdzk_timer_start": (i32, [vp]),
+        "amdzk_timer_stop": (i32, [vp, C.POINTER(C.c_float)]),
+        "amdzk_prof_enable": (i32, [vp, i32]),
+        "amdzk_prof_reset": (i32, [vp]),
+        "amdzk_prof_get": (i32, [vp, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+        "amdzk_prof_dump": (sz, [vp, C.c_char_p, sz]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    L._amdzk_sig = sig
+    _LIB = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def as_fr_array(a):
+    """(n,4) uint64 C-contiguous view/copy: n field elements, Montgomery limbs."""
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if a.ndim == 1:
+        a = a.reshape(-1, 4)
+    assert a.shape[-1] == 4
+    return a
+
+
+class DeviceBuffer:
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, nbytes
+        p = C.c_void_p()
+        ctx._chk(ctx.L.amdzk_dev_alloc(ctx.h, nbytes, C.byref(p)))
+        self.ptr = p
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.ctx._chk(self.ctx.L.amdzk_dev_upload(self.ctx.h, self.ptr, _ptr(arr), arr.nbytes))
+        return self
+
+    def download(self, shape, dtype=np.uint64):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        self.ctx._chk(self.ctx.L.amdzk_dev_download(self.ctx.h, _ptr(out), self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.L.amdzk_dev_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
+class Context:
+    """amdzk_ctx wrapper. Raises AmdzkError (never falls back to the CPU)."""
+
+    def __init__(self, device_id=0):
+        self.L = lib()
+        h = C.c_void_p()
+        rc = self.L.amdzk_init(device_id, C.byref(h))
+        if rc != 0:
+            raise AmdzkError(rc, "amdzk_init(%d) failed: no usable gfx950 device" % device_id)
+        self.h = h
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise AmdzkError(rc, self.L.amdzk_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.L.amdzk_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def sync(self):
+        self._chk(self.L.amdzk_sync(self.h))
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.L.amdzk_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    # ---- timing hooks
+    def timer_start(self):
+        self._chk(self.L.amdzk_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        self._chk(self.L.amdzk_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def prof_enable(self, on=True):
+        self._chk(self.L.amdzk_prof_enable(self.h, 1 if on else 0))
+
+    def prof_reset(self):
+        self._chk(self.L.amdzk_prof_reset(self.h))
+
+    def prof_dump(self):
+        need = self.L.amdzk_prof_dump(self.h, None, 0)
+        buf = C.create_string_buffer(need + 16)
+        self.L.amdzk_prof_dump(self.h, buf, need + 16)
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, n, ms = line.split()
+            out[name] = (int(n), float(ms))
+        return out

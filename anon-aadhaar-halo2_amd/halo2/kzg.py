@@ -1,0 +1,39 @@
+"""Mirror of halo2_proofs::poly::kzg::commitment::ParamsKZG (v2023_01_20 [UP]) — the resident part."""
+import ctypes as C
+
+import numpy as np
+
+from ..ffi import _ptr
+from . import arithmetic
+
+BASIS_G = 0
+BASIS_G_LAGRANGE = 1
+
+
+class ParamsKZG:
+    """Holds {k, n, g, g_lagrange} on the device. `g`/`g_lagrange`: (n, 8) uint64 affine points."""
+
+    def __init__(self, ctx, k, g=None, g_lagrange=None):
+        self.ctx, self.k, self.n = ctx, k, 1 << k
+        for a in (g, g_lagrange):
+            if a is not None:
+                assert a.shape == (self.n, 8) and a.dtype == np.uint64
+        self._g = None if g is None else np.ascontiguousarray(g)
+        self._gl = None if g_lagrange is None else np.ascontiguousarray(g_lagrange)
+        h = C.c_void_p()
+        ctx._chk(ctx.L.amdzk_srs_upload(ctx.h, None if g is None else _ptr(self._g),
+                                        None if g_lagrange is None else _ptr(self._gl), k, C.byref(h)))
+        self.h = h
+
+    def commit(self, poly_coeff):
+        """ParamsKZG::commit(poly, _blind): MSM with g[..len] (the blind is ignored for KZG)."""
+        return arithmetic.best_multiexp(self.ctx, self.h, BASIS_G, poly_coeff)
+
+    def commit_lagrange(self, poly_lagrange):
+        """ParamsKZG::commit_lagrange(poly, _blind): MSM with g_lagrange[..len]."""
+        return arithmetic.best_multiexp(self.ctx, self.h, BASIS_G_LAGRANGE, poly_lagrange)
+
+    def free(self):
+        if self.h:
+            self.ctx.L.amdzk_srs_free(self.ctx.h, self.h)
+            self.h = None

@@ -1,0 +1,119 @@
+/* amdzk — C ABI of the MI355X (gfx950) Halo2/KZG prover backend.
+ *
+ * This is the drop-in boundary. The reference (anon-aadhaar-halo2) consumes the
+ * prover only through the Rust API of
+ *     halo2_proofs 0.2.0 @ PSE v2023_01_20   (/root/reference/Cargo.lock:469-471)
+ *     halo2curves  0.3.1                      (/root/reference/Cargo.lock:484-486)
+ * re-exported by halo2-base (/root/reference/src/lib.rs:15-18, src/signal.rs:1-5,
+ * src/conditional_secrets.rs:1-5, src/timestamp.rs:1-4, src/chip.rs:6). A fork of halo2_proofs
+ * patched in with Cargo [patch] redirects the functions named next to each entry point below to
+ * this library (INTEGRATION.md shows the `extern "C"` block and the call sites).
+ *
+ * Number format = halo2curves' in-memory format, so Rust slices cross the boundary untouched:
+ *   Fr / Fq      : 4 x u64 little-endian limbs, Montgomery form, R = 2^256            (32 B)
+ *   G1Affine     : {x: Fq, y: Fq}; (0,0) is the identity                              (64 B)
+ *   G1 (Jacobian): {x, y, z: Fq}; z = 0 is the identity                               (96 B)
+ * Points returned by this library are always normalised: z = 1 (Montgomery one) or the identity
+ * (0, 1, 0) — equal as group elements to what the CPU prover computes; its own (x,y,z) depend on
+ * rayon's thread count, and every caller normalises before writing to the transcript.
+ *
+ * Ownership: the caller owns every host buffer; the library never keeps a host pointer after a call
+ * returns. Device objects are opaque handles freed by the caller.
+ * Errors: every function returns 0 on success and a negative amdzk_status on failure; the message is
+ * available from amdzk_last_error(). Nothing throws or aborts across this boundary.
+ * Threading: one amdzk_ctx per (GPU, host thread). Calls on one ctx are ordered on one HIP stream.
+ * There is NO CPU fallback: without a usable gfx950 device amdzk_init fails with AMDZK_E_NO_DEVICE.
+ */
+#ifndef AMDZK_H
+#define AMDZK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct amdzk_ctx amdzk_ctx;
+typedef struct amdzk_srs amdzk_srs;
+
+typedef enum {
+  AMDZK_OK = 0,
+  AMDZK_E_NO_DEVICE = -1,
+  AMDZK_E_INVALID = -2,   /* bad argument (null pointer, size mismatch, k out of range) */
+  AMDZK_E_HIP = -3,       /* a HIP runtime call failed */
+  AMDZK_E_NOMEM = -4,
+  AMDZK_E_UNSUPPORTED = -5
+} amdzk_status;
+
+/* basis selector for MSM: ParamsKZG.g (monomial) or ParamsKZG.g_lagrange */
+#define AMDZK_BASIS_G 0
+#define AMDZK_BASIS_G_LAGRANGE 1
+
+/* flags for amdzk_ntt_fr* */
+#define AMDZK_NTT_SCALE_NINV 1u /* multiply the result by 1/2^log_n (EvaluationDomain::ifft's divisor) */
+
+/* ---- context ------------------------------------------------------------------------------- */
+int amdzk_init(int device_id, amdzk_ctx** out);
+void amdzk_destroy(amdzk_ctx* ctx);
+const char* amdzk_last_error(const amdzk_ctx* ctx);
+/* ABI version of this header: major*1000 + minor. */
+int amdzk_version(void);
+/* Run subsequent work of this ctx on an existing hipStream_t (e.g. torch's current stream);
+ * NULL restores the ctx's own stream. */
+int amdzk_set_stream(amdzk_ctx* ctx, void* hip_stream);
+int amdzk_sync(amdzk_ctx* ctx);
+
+/* ---- device memory (plain hipMalloc'd bytes; any device pointer of the same GPU is accepted by
+ *      the *_dev entry points, including torch tensors' data_ptr()) ------------------------- */
+int amdzk_dev_alloc(amdzk_ctx* ctx, size_t bytes, void** dptr);
+int amdzk_dev_free(amdzk_ctx* ctx, void* dptr);
+int amdzk_dev_upload(amdzk_ctx* ctx, void* dptr, const void* host, size_t bytes);
+int amdzk_dev_download(amdzk_ctx* ctx, void* host, const void* dptr, size_t bytes);
+int amdzk_dev_memset(amdzk_ctx* ctx, void* dptr, int byte, size_t bytes);
+
+/* ---- SRS: replaces the resident part of poly::kzg::commitment::ParamsKZG {g, g_lagrange} [UP]
+ * g, g_lagrange: n = 2^k G1Affine each (either may be NULL if that basis is never used).
+ * The bases are uploaded once and expanded on the device into per-window multiples
+ * (2^(c*w) * g[i]) so that every MSM is bucket-accumulation only (MSM). */
+int amdzk_srs_upload(amdzk_ctx* ctx, const uint64_t* g, const uint64_t* g_lagrange, uint32_t k,
+                     amdzk_srs** out);
+void amdzk_srs_free(amdzk_ctx* ctx, amdzk_srs* srs);
+
+/* ---- MSM: replaces arithmetic::best_multiexp(coeffs, bases) as called from
+ * ParamsKZG::commit / commit_lagrange [UP].
+ * scalars: len x Fr (len <= 2^k; bases[0..len) are used, as `&g[..len]` in the original).
+ * out: one normalised Jacobian point (12 x u64). */
+int amdzk_msm_g1(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const uint64_t* scalars,
+                 size_t len, uint64_t out_jacobian[12]);
+/* ncols independent MSMs over the same bases in one submission (one per committed column). */
+int amdzk_msm_g1_batch(amdzk_ctx* ctx, const amdzk_srs* srs, int basis,
+                       const uint64_t* const* scalars, size_t ncols, size_t len,
+                       uint64_t* out_jacobian /* ncols x 12 */);
+/* Same, scalars already resident: column c starts at d_scalars + c*col_stride (in Fr elements). */
+int amdzk_msm_g1_dev(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const void* d_scalars,
+                     size_t ncols, size_t len, size_t col_stride,
+                     uint64_t* out_jacobian /* host, ncols x 12 */);
+
+/* ---- NTT: replaces arithmetic::best_fft(a, omega, log_n) [UP] (rows a3, a4).
+ * In place, natural order in, natural order out: a[j] <- sum_i a[i] * omega^(i*j). */
+int amdzk_ntt_fr(amdzk_ctx* ctx, uint64_t* a, uint32_t log_n, const uint64_t omega[4],
+                 uint32_t flags);
+/* ncols resident columns, column c at d_a + c*col_stride (Fr elements), each of 2^log_n. */
+int amdzk_ntt_fr_dev(amdzk_ctx* ctx, void* d_a, uint32_t log_n, const uint64_t omega[4],
+                     uint32_t flags, size_t ncols, size_t col_stride);
+
+/* ---- timing / profiling hooks used by bench.py (HIP events on this ctx's stream) ------------ */
+int amdzk_timer_start(amdzk_ctx* ctx);
+int amdzk_timer_stop(amdzk_ctx* ctx, float* ms); /* synchronises on the stop event */
+/* When enabled, every kernel launch of this ctx is bracketed by HIP events; query by kernel name. */
+int amdzk_prof_enable(amdzk_ctx* ctx, int on);
+int amdzk_prof_reset(amdzk_ctx* ctx);
+int amdzk_prof_get(amdzk_ctx* ctx, const char* kernel_name, uint64_t* launches, double* total_ms);
+/* Writes a '\n'-separated list "name launches total_ms" into buf. Returns bytes needed. */
+size_t amdzk_prof_dump(amdzk_ctx* ctx, char* buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMDZK_H */

@@ -1,0 +1,111 @@
+"""GPU parity: amdzk_msm_g1* (HIP, gfx950) vs the oracle's best_multiexp restatement. Equality is on
+the affine point (the reference's projective coordinates depend on rayon's thread count)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import zkutil as zu
+
+pytestmark = pytest.mark.gpu
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bn254_golden.json")))
+
+
+@pytest.fixture(scope="module")
+def srs14(oracle):
+    return oracle.srs_powers(zu.fr_from_int(0xABCDEF12345), 1 << 14)
+
+
+def check(ctx, pkg, oracle, params, bases, scalars, basis=0):
+    got = pkg.arithmetic.best_multiexp(ctx, params.h, basis, scalars)
+    want = oracle.best_multiexp(scalars, bases[: scalars.shape[0]])
+    assert np.array_equal(zu.jac_to_affine_host(oracle, got), want)
+
+
+def test_msm_golden_vectors(ctx, pkg, oracle):
+    srs = np.array([zu.point_from_ints((int(p[0], 16), int(p[1], 16))) for p in G["srs"]["g"]], dtype=np.uint64)
+    params = pkg.kzg.ParamsKZG(ctx, 6, g=srs)
+    for v in G["msm"]:
+        s = zu.fr_array_from_ints([int(x, 16) for x in v["scalars"]])
+        got = zu.point_to_ints(zu.jac_to_affine_host(oracle, params.commit(s)))
+        want = None if v["result"] is None else (int(v["result"][0], 16), int(v["result"][1], 16))
+        assert got == want, v["kind"]
+    params.free()
+
+
+@pytest.mark.parametrize("k", [1, 4, 8, 10, 11, 12, 13, 14])
+def test_msm_uniform_matches_oracle(ctx, pkg, oracle, srs14, k):
+    n = 1 << k
+    params = pkg.kzg.ParamsKZG(ctx, k, g=srs14[:n].copy())
+    check(ctx, pkg, oracle, params, srs14, zu.random_fr(n, seed=300 + k))
+    params.free()
+
+
+def test_msm_edge_cases(ctx, pkg, oracle, srs14):
+    k = 10
+    n = 1 << k
+    params = pkg.kzg.ParamsKZG(ctx, k, g=srs14[:n].copy(), g_lagrange=srs14[n:2 * n].copy())
+    one = zu.fr_from_int(1)
+    zeros = np.zeros((n, 4), np.uint64)
+    # all zero -> identity in normal form (0,1,0)
+    got = params.commit(zeros)
+    assert zu.point_to_ints(zu.jac_to_affine_host(oracle, got)) is None
+    # empty and ragged lengths (bases[..len])
+    for m in (0, 1, 2, 3, 31, 33, 1000):
+        check(ctx, pkg, oracle, params, srs14, zu.random_fr(m, seed=m + 1) if m else np.zeros((0, 4), np.uint64))
+    # all ones: every digit lands in one bucket (heavy-bucket path)
+    check(ctx, pkg, oracle, params, srs14, np.tile(one, (n, 1)))
+    # r-1 (= -1), 2^k-boundaries of the window digits, skewed witness-like column
+    check(ctx, pkg, oracle, params, srs14, np.tile(zu.fr_from_int(zu.R - 1), (n, 1)))
+    edge = zu.fr_array_from_ints([[0, 1, zu.R - 1, 127, 128, 129, 255, 256, (1 << 253) % zu.R, (1 << 64) - 1][i % 10] for i in range(n)])
+    check(ctx, pkg, oracle, params, srs14, edge)
+    check(ctx, pkg, oracle, params, srs14, zu.skewed_fr(n, 77, oracle))
+    # second basis
+    check(ctx, pkg, oracle, params, srs14[n:], zu.random_fr(n, seed=5), basis=1)
+    params.free()
+
+
+def test_msm_repeated_and_identity_bases(ctx, pkg, oracle):
+    """Bases that collide (same point many times, P and -P, identity): exercises the doubling and
+    cancellation branches of the mixed addition."""
+    k = 8
+    n = 1 << k
+    gen = oracle.generator()
+    neg = zu.point_from_ints((1, zu.Q - 2))
+    bases = np.tile(gen, (n, 1))
+    bases[1::3] = neg
+    bases[2::7] = 0
+    params = pkg.kzg.ParamsKZG(ctx, k, g=bases)
+    for seed, s in ((1, zu.random_fr(n, seed=41)), (2, np.tile(zu.fr_from_int(1), (n, 1))), (3, zu.skewed_fr(n, 3, oracle))):
+        check(ctx, pkg, oracle, params, bases, s)
+    params.free()
+
+
+def test_msm_batch_columns(ctx, pkg, oracle, srs14):
+    k, ncols = 12, 7
+    n = 1 << k
+    params = pkg.kzg.ParamsKZG(ctx, k, g_lagrange=srs14[:n].copy())
+    cols = [zu.skewed_fr(n, 50 + c, oracle) if c % 2 else zu.random_fr(n, seed=60 + c) for c in range(ncols)]
+    cols[3] = np.zeros((n, 4), np.uint64)
+    got = pkg.arithmetic.best_multiexp_batch(ctx, params.h, 1, cols)
+    for c in range(ncols):
+        assert np.array_equal(zu.jac_to_affine_host(oracle, got[c]), oracle.best_multiexp(cols[c], srs14[:n]))
+    params.free()
+
+
+def test_msm_linearity_large(ctx, pkg, oracle):
+    """Size-independent property at a size the naive oracle cannot reach quickly: with bases
+    g_i = t^i G (known t), MSM(s, g) = (sum s_i t^i) G = eval_polynomial(s, t) * G."""
+    k = 16
+    n = 1 << k
+    tau = zu.fr_from_int(123456789)
+    g = oracle.srs_powers(tau, n)
+    params = pkg.kzg.ParamsKZG(ctx, k, g=g)
+    s = zu.random_fr(n, seed=8)
+    got = zu.jac_to_affine_host(oracle, params.commit(s))
+    e = oracle.eval_polynomial(s, tau)
+    want = oracle.g1_mul_many(oracle.generator(), e.reshape(1, 4))[0]
+    assert np.array_equal(got, want)
+    assert np.array_equal(got, oracle.best_multiexp(s, g))
+    params.free()
