@@ -203,14 +203,6 @@ __global__ void twiddle_gen_kernel(Fr* tw, Fr omega, uint32_t count, uint32_t ch
   }
 }
 
-__global__ void copy_cols_kernel(const uint4* src, uint4* dst, size_t n16, size_t src_stride16,
-                                 size_t dst_stride16) {
-  const uint4* s = src + (size_t)blockIdx.y * src_stride16;
-  uint4* d = dst + (size_t)blockIdx.y * dst_stride16;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
-    d[i] = s[i];
-}
-
 int get_twiddles(amdzk_ctx* ctx, uint32_t log_n, const uint64_t omega[4], Fr** out) {
   TwiddleKey key;
   key.log_n = log_n;
@@ -268,24 +260,25 @@ Plan make_plan(uint32_t log_n, uint32_t tile_log) {
 
 }  // namespace
 
-// Generalised entry used by the C ABI and by the domain helpers.
+// Generalised entry used by the C ABI and by the domain helpers. Out of place when d_in != d_out.
 //   in_len   : number of valid input elements per column (rest read as zero); 0 means n.
 //   in_coset : if non-null, 2 constants applied to input element i with i%3 = 1, 2
 //   out_mul  : if non-null, 3 constants applied to output element j by j%3
-int zk_ntt_ex(amdzk_ctx* ctx, Fr* d_a, uint32_t log_n, const uint64_t omega[4], size_t ncols,
-              size_t col_stride, uint32_t in_len, const Fr* in_coset, const Fr* out_mul) {
+int zk_ntt_ex(amdzk_ctx* ctx, const Fr* d_in, size_t in_stride, Fr* d_out, size_t out_stride, uint32_t log_n,
+              const uint64_t omega[4], size_t ncols, uint32_t in_len, const Fr* in_coset, const Fr* out_mul) {
   if (log_n > 27) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "ntt: log_n %u > 27", log_n);
   if (ncols == 0) return AMDZK_OK;
   const size_t n = (size_t)1 << log_n;
-  if (ncols > 1 && col_stride < n) ZK_FAIL(ctx, AMDZK_E_INVALID, "ntt: col_stride < n");
+  if (in_len == 0 || in_len > n) in_len = (uint32_t)n;
+  if (ncols > 1 && (out_stride < n || in_stride < in_len)) ZK_FAIL(ctx, AMDZK_E_INVALID, "ntt: column stride too small");
   if (ncols > 65535) ZK_FAIL(ctx, AMDZK_E_INVALID, "ntt: more than 65535 columns in one call");
   Fr* tw = nullptr;
   ZK_TRY(get_twiddles(ctx, log_n, omega, &tw));
-  const uint32_t tile_log = env_u32("AMDZK_NTT_TILE_LOG", 10);
+  const uint32_t tile_log = env_u32("AMDZK_NTT_TILE_LOG", 11);
   Plan plan = make_plan(log_n, tile_log);
 
   Fr* ws = nullptr;
-  ZK_TRY(zk_ws_reserve(ctx, 0, ncols * n * sizeof(Fr), (void**)&ws));
+  if (plan.npass > 1) ZK_TRY(zk_ws_reserve(ctx, 0, ncols * n * sizeof(Fr), (void**)&ws));
 
   NttPassArgs a;
   memset(&a, 0, sizeof(a));
@@ -294,7 +287,7 @@ int zk_ntt_ex(amdzk_ctx* ctx, Fr* d_a, uint32_t log_n, const uint64_t omega[4], 
   a.npass = plan.npass;
   a.log_n1 = plan.s[0];
   a.log_n2 = plan.s[1];
-  a.in_len = in_len ? in_len : (uint32_t)n;
+  a.in_len = in_len;
   if (in_coset) {
     a.in_c[0] = in_coset[0];
     a.in_c[1] = in_coset[1];
@@ -322,37 +315,39 @@ int zk_ntt_ex(amdzk_ctx* ctx, Fr* d_a, uint32_t log_n, const uint64_t omega[4], 
     a.flags = 0;
     if (p == 0 && in_coset) a.flags |= F_IN_COSET;
     if (last && out_mul) a.flags |= F_OUT_MUL;
-    // buffers: first step reads the caller's column, last step writes it; in between the workspace.
-    bool in_is_user = (p == 0);
-    bool out_is_user = last && plan.npass > 1;
-    a.in = in_is_user ? d_a : ws;
-    a.in_col_stride = in_is_user ? col_stride : n;
-    a.out = out_is_user ? d_a : ws;
-    a.out_col_stride = out_is_user ? col_stride : n;
-    if (plan.npass == 1) {  // single tile per column: in place is safe (all loads precede all stores)
-      a.out = d_a;
-      a.out_col_stride = col_stride;
-    }
+    // first step reads the caller's input, last step writes the caller's output, the workspace
+    // carries the intermediate layout. A single-step transform covers a column with one tile (all
+    // loads precede all stores), so it may run in place.
+    a.in = (p == 0) ? d_in : ws;
+    a.in_col_stride = (p == 0) ? in_stride : n;
+    a.out = last ? d_out : ws;
+    a.out_col_stride = last ? out_stride : n;
     const uint32_t tile_elems_log = a.s + a.log_c;
     dim3 grid((uint32_t)(n >> tile_elems_log), (uint32_t)ncols), block(NTT_THREADS);
     size_t shmem = (((size_t)1 << tile_elems_log) + ((size_t)1 << a.s) / 2 + 1) * sizeof(Fr);
-    if (last)
+    if (last) {
+      if (shmem > 65536) ZK_HIP(ctx, hipFuncSetAttribute((const void*)ntt_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
       ZK_LAUNCH(ctx, "ntt_step_last", ntt_step_kernel<true>, grid, block, shmem, a);
-    else
+    } else {
+      if (shmem > 65536) ZK_HIP(ctx, hipFuncSetAttribute((const void*)ntt_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
       ZK_LAUNCH(ctx, "ntt_step", ntt_step_kernel<false>, grid, block, shmem, a);
+    }
     log_prev += a.s;
   }
   return AMDZK_OK;
 }
 
+Fr zk_fr_inv_pow2(uint32_t log_n) {
+  Fr two = add(Fr::one(), Fr::one());
+  return inv(pow_u64(two, log_n));
+}
+
 int zk_ntt_dev(amdzk_ctx* ctx, Fr* d_a, uint32_t log_n, const uint64_t omega[4], uint32_t flags,
                size_t ncols, size_t col_stride) {
   if (flags & AMDZK_NTT_SCALE_NINV) {
-    // 1/n as a Montgomery constant: (2^log_n)^-1
-    Fr two = add(Fr::one(), Fr::one());
-    Fr ninv = inv(pow_u64(two, log_n));
+    Fr ninv = zk_fr_inv_pow2(log_n);
     Fr oc[3] = {ninv, ninv, ninv};
-    return zk_ntt_ex(ctx, d_a, log_n, omega, ncols, col_stride, 0, nullptr, oc);
+    return zk_ntt_ex(ctx, d_a, col_stride, d_a, col_stride, log_n, omega, ncols, 0, nullptr, oc);
   }
-  return zk_ntt_ex(ctx, d_a, log_n, omega, ncols, col_stride, 0, nullptr, nullptr);
+  return zk_ntt_ex(ctx, d_a, col_stride, d_a, col_stride, log_n, omega, ncols, 0, nullptr, nullptr);
 }

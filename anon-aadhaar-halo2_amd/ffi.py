@@ -47,6 +47,18 @@ def lib():
         "amdzk_msm_g1_dev": (i32, [vp, vp, i32, vp, sz, sz, sz, vp]),
         "amdzk_ntt_fr": (i32, [vp, vp, u32, vp, u32]),
         "amdzk_ntt_fr_dev": (i32, [vp, vp, u32, vp, u32, sz, sz]),
+        "amdzk_fr_from_raw_dev": (i32, [vp, vp, sz]),
+        "amdzk_fr_to_repr_dev": (i32, [vp, vp, sz]),
+        "amdzk_domain_new": (i32, [vp, u32, u32, C.POINTER(vp)]),
+        "amdzk_domain_free": (None, [vp, vp]),
+        "amdzk_domain_k": (u32, [vp]),
+        "amdzk_domain_extended_k": (u32, [vp]),
+        "amdzk_domain_constant": (i32, [vp, i32, vp]),
+        "amdzk_lagrange_to_coeff_dev": (i32, [vp, vp, vp, sz, sz]),
+        "amdzk_coeff_to_lagrange_dev": (i32, [vp, vp, vp, sz, sz]),
+        "amdzk_coeff_to_extended_dev": (i32, [vp, vp, vp, sz, vp, sz, sz]),
+        "amdzk_extended_to_coeff_dev": (i32, [vp, vp, vp, sz, sz]),
+        "amdzk_divide_by_vanishing_dev": (i32, [vp, vp, vp, sz, sz]),
         "amdzk_timer_start": (i32, [vp]),
         "amdzk_timer_stop": (i32, [vp, C.POINTER(C.c_float)]),
         "amdzk_prof_enable": (i32, [vp, i32]),

@@ -1,2 +1,90 @@
-"""Mirror of halo2_proofs::poly::domain::EvaluationDomain (v2023_01_20 [UP]) — filled in as the
-device side of each method lands. Host constants only here; O(n) work is always on the device."""
+"""Mirror of halo2_proofs::poly::domain::EvaluationDomain (v2023_01_20 [UP]).
+
+Host side holds only the O(1) constants; every O(n) method runs on the device through the C ABI.
+Polynomials are numpy (len, 4) uint64 arrays on the host or DeviceBuffer columns on the device."""
+import ctypes as C
+
+import numpy as np
+
+from ..ffi import _ptr, as_fr_array
+
+_CONSTS = ("omega", "omega_inv", "extended_omega", "extended_omega_inv", "g_coset", "g_coset_inv",
+           "ifft_divisor", "extended_ifft_divisor")
+
+
+class EvaluationDomain:
+    def __init__(self, ctx, j, k):
+        """EvaluationDomain::new(j, k): j = constraint-system degree, n = 2^k."""
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._chk(ctx.L.amdzk_domain_new(ctx.h, j, k, C.byref(h)))
+        self.h = h
+        self.k = ctx.L.amdzk_domain_k(h)
+        self.extended_k = ctx.L.amdzk_domain_extended_k(h)
+        self.n = 1 << self.k
+        self.quotient_poly_degree = j - 1
+        for i, name in enumerate(_CONSTS):
+            v = np.zeros(4, np.uint64)
+            ctx._chk(ctx.L.amdzk_domain_constant(h, i, _ptr(v)))
+            setattr(self, name, v)
+
+    def extended_len(self):
+        return 1 << self.extended_k
+
+    def free(self):
+        if self.h:
+            self.ctx.L.amdzk_domain_free(self.ctx.h, self.h)
+            self.h = None
+
+    # ---- device-resident forms (what the prover uses)
+    def lagrange_to_coeff_dev(self, dbuf, ncols=1, col_stride=None):
+        self.ctx._chk(self.ctx.L.amdzk_lagrange_to_coeff_dev(self.ctx.h, self.h, dbuf.ptr, ncols, col_stride or self.n))
+
+    def coeff_to_lagrange_dev(self, dbuf, ncols=1, col_stride=None):
+        self.ctx._chk(self.ctx.L.amdzk_coeff_to_lagrange_dev(self.ctx.h, self.h, dbuf.ptr, ncols, col_stride or self.n))
+
+    def coeff_to_extended_dev(self, d_coeff, d_ext, ncols=1, in_stride=None, out_stride=None):
+        self.ctx._chk(self.ctx.L.amdzk_coeff_to_extended_dev(
+            self.ctx.h, self.h, d_coeff.ptr, in_stride or self.n, d_ext.ptr, out_stride or self.extended_len(), ncols))
+
+    def extended_to_coeff_dev(self, d_ext, ncols=1, col_stride=None):
+        self.ctx._chk(self.ctx.L.amdzk_extended_to_coeff_dev(self.ctx.h, self.h, d_ext.ptr, ncols, col_stride or self.extended_len()))
+
+    def divide_by_vanishing_poly_dev(self, d_ext, ncols=1, col_stride=None):
+        self.ctx._chk(self.ctx.L.amdzk_divide_by_vanishing_dev(self.ctx.h, self.h, d_ext.ptr, ncols, col_stride or self.extended_len()))
+
+    # ---- host-array conveniences with the upstream names (upload, run, download)
+    def _roundtrip(self, a, fn, out_len=None):
+        a = as_fr_array(a)
+        buf = self.ctx.alloc(max(a.nbytes, 32)).upload(a)
+        fn(buf)
+        out = buf.download((out_len or a.shape[0], 4))
+        buf.free()
+        return out
+
+    def lagrange_to_coeff(self, a):
+        assert len(a) == self.n
+        return self._roundtrip(a, self.lagrange_to_coeff_dev)
+
+    def coeff_to_lagrange(self, a):
+        assert len(a) == self.n
+        return self._roundtrip(a, self.coeff_to_lagrange_dev)
+
+    def coeff_to_extended(self, a):
+        a = as_fr_array(a)
+        assert a.shape[0] == self.n
+        src = self.ctx.alloc(a.nbytes).upload(a)
+        dst = self.ctx.alloc(self.extended_len() * 32)
+        self.coeff_to_extended_dev(src, dst)
+        out = dst.download((self.extended_len(), 4))
+        src.free()
+        dst.free()
+        return out
+
+    def extended_to_coeff(self, a):
+        assert len(a) == self.extended_len()
+        return self._roundtrip(a, self.extended_to_coeff_dev)[: self.n * self.quotient_poly_degree]
+
+    def divide_by_vanishing_poly(self, a):
+        assert len(a) == self.extended_len()
+        return self._roundtrip(a, self.divide_by_vanishing_poly_dev)

@@ -103,6 +103,39 @@ int amdzk_ntt_fr(amdzk_ctx* ctx, uint64_t* a, uint32_t log_n, const uint64_t ome
 int amdzk_ntt_fr_dev(amdzk_ctx* ctx, void* d_a, uint32_t log_n, const uint64_t omega[4],
                      uint32_t flags, size_t ncols, size_t col_stride);
 
+/* ---- representation changes on resident data: Fr::from_raw (canonical 4 x u64 -> Montgomery) and
+ * Fr::to_repr (Montgomery -> canonical), n elements in place. Values must be < r. */
+int amdzk_fr_from_raw_dev(amdzk_ctx* ctx, void* d_a, size_t n);
+int amdzk_fr_to_repr_dev(amdzk_ctx* ctx, void* d_a, size_t n);
+
+/* ---- EvaluationDomain: replaces poly::domain::EvaluationDomain [UP] (rows a4-a6).
+ * amdzk_domain_new(j, k) = EvaluationDomain::new(j, k): j = cs.degree(), n = 2^k,
+ * extended_k = smallest e with 2^e >= n*(j-1). Columns are device-resident; `col_stride` and the
+ * in/out strides are in Fr elements. */
+typedef struct amdzk_domain amdzk_domain;
+int amdzk_domain_new(amdzk_ctx* ctx, uint32_t j, uint32_t k, amdzk_domain** out);
+void amdzk_domain_free(amdzk_ctx* ctx, amdzk_domain* dom);
+uint32_t amdzk_domain_k(const amdzk_domain* dom);
+uint32_t amdzk_domain_extended_k(const amdzk_domain* dom);
+/* what: 0 omega, 1 omega_inv, 2 extended_omega, 3 extended_omega_inv, 4 g_coset (= Fr::ZETA),
+ * 5 g_coset_inv, 6 ifft_divisor, 7 extended_ifft_divisor */
+int amdzk_domain_constant(const amdzk_domain* dom, int what, uint64_t out[4]);
+/* lagrange_to_coeff / coeff_to_lagrange: in place on ncols columns of 2^k. */
+int amdzk_lagrange_to_coeff_dev(amdzk_ctx* ctx, const amdzk_domain* dom, void* d_cols, size_t ncols,
+                                size_t col_stride);
+int amdzk_coeff_to_lagrange_dev(amdzk_ctx* ctx, const amdzk_domain* dom, void* d_cols, size_t ncols,
+                                size_t col_stride);
+/* coeff_to_extended: 2^k coefficients in -> 2^extended_k evaluations on the zeta coset out
+ * (distribute_powers_zeta, zero padding and the NTT in one pass structure). d_ext != d_coeff. */
+int amdzk_coeff_to_extended_dev(amdzk_ctx* ctx, const amdzk_domain* dom, const void* d_coeff,
+                                size_t in_stride, void* d_ext, size_t out_stride, size_t ncols);
+/* extended_to_coeff: in place on 2^extended_k values; the first n*(j-1) entries are the result. */
+int amdzk_extended_to_coeff_dev(amdzk_ctx* ctx, const amdzk_domain* dom, void* d_ext, size_t ncols,
+                                size_t col_stride);
+/* divide_by_vanishing_poly: a[i] *= 1/((zeta*extended_omega^i)^n - 1), in place. */
+int amdzk_divide_by_vanishing_dev(amdzk_ctx* ctx, const amdzk_domain* dom, void* d_ext, size_t ncols,
+                                  size_t col_stride);
+
 /* ---- timing / profiling hooks used by bench.py (HIP events on this ctx's stream) ------------ */
 int amdzk_timer_start(amdzk_ctx* ctx);
 int amdzk_timer_stop(amdzk_ctx* ctx, float* ms); /* synchronises on the stop event */

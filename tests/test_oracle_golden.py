@@ -105,3 +105,18 @@ def test_batch_invert(oracle):
     got = oracle.batch_invert(a)
     want = oracle.fr_inv(a)
     assert np.array_equal(got, want) and not got[7].any()
+
+
+def test_evaluation_domain(oracle):
+    v = G["domain"]
+    d = zu.OracleDomain(oracle, v["j"], v["k"])
+    assert d.extended_k == v["extended_k"]
+    coeff = zu.fr_array_from_ints([I(x) for x in v["coeff"]])
+    assert zu.fr_array_to_ints(d.coeff_to_lagrange(coeff)) == [I(x) for x in v["lagrange"]]
+    assert np.array_equal(d.lagrange_to_coeff(d.coeff_to_lagrange(coeff)), coeff)
+    ext = d.coeff_to_extended(coeff)
+    assert zu.fr_array_to_ints(ext) == [I(x) for x in v["extended"]]
+    assert zu.fr_array_to_ints(d.t_evaluations) == [I(x) for x in v["t_evaluations"]]
+    assert zu.fr_array_to_ints(d.divide_by_vanishing_poly(ext)) == [I(x) for x in v["divided"]]
+    back = d.extended_to_coeff(ext)
+    assert np.array_equal(back[: d.n], coeff) and not back[d.n:].any()

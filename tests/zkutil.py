@@ -96,7 +96,10 @@ class Oracle:
             subprocess.check_call(["make"], cwd=os.path.join(ROOT, "oracle"))
         self.L = C.CDLL(path)
         self.L.oracle_max_threads.restype = C.c_int
-        self.threads = self.L.oracle_max_threads()
+        # A one-GPU box gives this job a 16-core share of the host (the pool's rule), whatever
+        # omp_get_max_threads() reports; oversubscribing it only adds noise.
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        self.threads = max(1, min(self.L.oracle_max_threads(), avail, int(os.environ.get("ORACLE_THREADS", "16"))))
 
     def _bin(self, fn, a, b):
         a, b = np.ascontiguousarray(a, np.uint64), np.ascontiguousarray(b, np.uint64)
@@ -194,6 +197,57 @@ class Oracle:
     def batch_invert(self, a):
         a = np.ascontiguousarray(a, np.uint64).copy()
         self.L.oracle_batch_invert(_p(a), C.c_size_t(a.shape[0]))
+        return a
+
+
+class OracleDomain:
+    """oracle/oracle_domain.cpp: EvaluationDomain restatement."""
+    NAMES = ("omega", "omega_inv", "extended_omega", "extended_omega_inv", "g_coset", "g_coset_inv",
+             "ifft_divisor", "extended_ifft_divisor")
+
+    def __init__(self, oracle, j, k):
+        self.o, self.L = oracle, oracle.L
+        self.L.oracle_domain_new.restype = C.c_void_p
+        self.L.oracle_domain_extended_k.restype = C.c_uint32
+        self.L.oracle_domain_t_len.restype = C.c_uint32
+        self.h = C.c_void_p(self.L.oracle_domain_new(C.c_uint32(j), C.c_uint32(k)))
+        self.k, self.n, self.j = k, 1 << k, j
+        self.extended_k = self.L.oracle_domain_extended_k(self.h)
+        for i, nm in enumerate(self.NAMES):
+            v = np.zeros(4, np.uint64)
+            self.L.oracle_domain_constant(self.h, C.c_int(i), _p(v))
+            setattr(self, nm, v)
+        t = np.zeros((self.L.oracle_domain_t_len(self.h), 4), np.uint64)
+        self.L.oracle_domain_t_evaluations(self.h, _p(t))
+        self.t_evaluations = t
+
+    def extended_len(self):
+        return 1 << self.extended_k
+
+    def lagrange_to_coeff(self, a):
+        a = np.ascontiguousarray(a, np.uint64).copy()
+        self.L.oracle_lagrange_to_coeff(self.h, _p(a), C.c_int(self.o.threads))
+        return a
+
+    def coeff_to_lagrange(self, a):
+        a = np.ascontiguousarray(a, np.uint64).copy()
+        self.L.oracle_coeff_to_lagrange(self.h, _p(a), C.c_int(self.o.threads))
+        return a
+
+    def coeff_to_extended(self, a):
+        a = np.ascontiguousarray(a, np.uint64)
+        out = np.zeros((self.extended_len(), 4), np.uint64)
+        self.L.oracle_coeff_to_extended(self.h, _p(a), _p(out), C.c_int(self.o.threads))
+        return out
+
+    def extended_to_coeff(self, a):
+        a = np.ascontiguousarray(a, np.uint64).copy()
+        self.L.oracle_extended_to_coeff(self.h, _p(a), C.c_int(self.o.threads))
+        return a[: self.n * (self.j - 1)]
+
+    def divide_by_vanishing_poly(self, a):
+        a = np.ascontiguousarray(a, np.uint64).copy()
+        self.L.oracle_divide_by_vanishing_poly(self.h, _p(a))
         return a
 
 
