@@ -40,3 +40,14 @@ def test_no_cpu_fallback(pkg):
         pytest.skip("a GPU is present; covered by the gpu tests")
     with pytest.raises(pkg.AmdzkError):
         pkg.Context(0)
+
+
+def test_product_does_not_touch_oracle():
+    """No file of the shipped package (Python or C++/HIP) references oracle/ or pyref."""
+    pkg_dir = os.path.join(ROOT, "anon-aadhaar-halo2_amd")
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cuh", ".cpp", ".h")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                for needle in ("oracle/", "liboracle", "pyref", "bn254_ref", "zkutil"):
+                    assert needle not in text, "%s references %s" % (os.path.join(dirpath, f), needle)
