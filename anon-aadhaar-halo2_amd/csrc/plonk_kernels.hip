@@ -1,0 +1,395 @@
+// Device kernels of the PLONK-specific part of create_proof (halo2_proofs 0.2.0 @ v2023_01_20 [UP],
+// /root/reference/Cargo.lock:469-471):
+//
+//   expr_eval_kernel   — plonk::evaluation::Evaluator::evaluate_h (a7) and every other "evaluate an
+//                        expression on all rows" loop of the prover (lookup compression a9, the
+//                        numerators/denominators of the permutation and lookup grand products a8):
+//                        one straight-line stack program, executed by every row in lock step.
+//   batch_invert_kernel, scan_* kernels — BatchInvert + the running products z(X) (a8, a9)
+//   poly_eval_kernel   — arithmetic::eval_polynomial for all (polynomial, point) queries at once (a11)
+//   lincomb_kernel, kate_div_kernel, small helpers — SHPLONK's polynomial algebra (a12)
+//
+// Upstream walks a per-row "calculation graph" on CPU threads; here the host compiles the whole h(X)
+// numerator (custom gates, permutation and lookup terms, folded with y) into ONE postfix program
+// whose instruction stream is wave-uniform (scalar loads / scalar branches) while the data path is
+// one row per lane: column reads are 32-B-per-lane contiguous, the operand stack lives in LDS with
+// the top of stack in registers.
+#include <stdlib.h>
+#include <string.h>
+
+#include "plonk_kernels.hpp"
+
+using namespace bn254;
+
+namespace {
+
+__device__ __forceinline__ Fr ld_fr(const Fr* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 a = q[0], b = q[1];
+  Fr r;
+  r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+  r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+  return r;
+}
+__device__ __forceinline__ void st_fr(Fr* p, const Fr& v) {
+  uint4* q = reinterpret_cast<uint4*>(p);
+  q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+// ------------------------------------------------------------------------------ interpreter
+__global__ __launch_bounds__(EXPR_THREADS) void expr_eval_kernel(ExprArgs a) {
+  extern __shared__ uint4 lds_raw[];
+  Fr* stack = reinterpret_cast<Fr*>(lds_raw);  // [depth][EXPR_THREADS]
+  const uint32_t tid = threadIdx.x;
+  const size_t row = (size_t)blockIdx.x * EXPR_THREADS + tid;
+  if (row >= a.nrows) return;  // domains smaller than one block (no barriers below, so an early exit is safe)
+  Fr tos = Fr::zero();
+  Fr h = Fr::zero();
+  const Fr yv = ld_fr(a.consts + a.y_const);
+  uint32_t sp = 0;  // elements on the stack, including tos
+  for (uint32_t pc = 0; pc < a.prog_len; pc++) {
+    const uint32_t w = a.prog[pc];
+    const uint32_t op = w >> 24, arg = w & 0xffffffu;
+    switch (op) {
+      case OP_PUSH_COL:
+      case OP_MUL_COL:
+      case OP_ADD_COL:
+      case OP_SUB_COL: {
+        const Fr* col = a.cols[arg >> 8];
+        const size_t idx = (row + (size_t)(int64_t)a.rot_off[arg & 0xff]) & a.mask;
+        Fr v = ld_fr(col + idx);
+        if (op == OP_PUSH_COL) {
+          if (sp > 0) stack[(sp - 1) * EXPR_THREADS + tid] = tos;
+          tos = v;
+          sp++;
+        } else if (op == OP_MUL_COL) {
+          tos = mul(tos, v);
+        } else if (op == OP_ADD_COL) {
+          tos = add(tos, v);
+        } else {
+          tos = sub(tos, v);
+        }
+      } break;
+      case OP_PUSH_CONST:
+        if (sp > 0) stack[(sp - 1) * EXPR_THREADS + tid] = tos;
+        tos = ld_fr(a.consts + arg);
+        sp++;
+        break;
+      case OP_MUL_CONST:
+        tos = mul(tos, ld_fr(a.consts + arg));
+        break;
+      case OP_ADD_CONST:
+        tos = add(tos, ld_fr(a.consts + arg));
+        break;
+      case OP_ADD:
+        tos = add(stack[(sp - 2) * EXPR_THREADS + tid], tos);
+        sp--;
+        break;
+      case OP_SUB:
+        tos = sub(stack[(sp - 2) * EXPR_THREADS + tid], tos);
+        sp--;
+        break;
+      case OP_MUL:
+        tos = mul(stack[(sp - 2) * EXPR_THREADS + tid], tos);
+        sp--;
+        break;
+      case OP_NEG:
+        tos = neg(tos);
+        break;
+      case OP_SQR:
+        tos = sqr(tos);
+        break;
+      case OP_ACC:  // h = h*y + value
+        h = add(mul(h, yv), tos);
+        sp--;
+        if (sp > 0) tos = stack[(sp - 1) * EXPR_THREADS + tid];
+        break;
+      case OP_STORE:
+        st_fr(a.outs[arg] + row, tos);
+        sp--;
+        if (sp > 0) tos = stack[(sp - 1) * EXPR_THREADS + tid];
+        break;
+      default:
+        break;
+    }
+  }
+  if (a.h_out) st_fr(a.h_out + row, h);
+}
+
+// ------------------------------------------------------------------------------ batch inversion
+// In place over a flat array; zeros stay zero (ff::BatchInvert). One Fermat inversion per chunk.
+__global__ __launch_bounds__(256) void batch_invert_kernel(Fr* a, Fr* scratch, size_t total, uint32_t chunk) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t s = t * chunk;
+  if (s >= total) return;
+  const size_t e = s + chunk < total ? s + chunk : total;
+  Fr acc = Fr::one();
+  for (size_t i = s; i < e; i++) {
+    st_fr(scratch + i, acc);
+    Fr v = ld_fr(a + i);
+    if (!v.is_zero()) acc = mul(acc, v);
+  }
+  acc = inv(acc);
+  for (size_t i = e; i-- > s;) {
+    Fr v = ld_fr(a + i);
+    if (v.is_zero()) continue;
+    st_fr(a + i, mul(acc, ld_fr(scratch + i)));
+    acc = mul(acc, v);
+  }
+}
+
+// a[i] = a[i] * b[i]
+__global__ __launch_bounds__(256) void mul_elem_kernel(Fr* a, const Fr* b, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    st_fr(a + i, mul(ld_fr(a + i), ld_fr(b + i)));
+}
+
+// ------------------------------------------------------------------------------ running products
+// Exclusive prefix product of each column, three steps. Block = 256 threads x SCAN_E elements.
+constexpr int SCAN_E = 8;
+constexpr int SCAN_BLOCK = 256 * SCAN_E;
+
+__global__ __launch_bounds__(256) void scan_local_kernel(const Fr* in, Fr* out, Fr* totals, size_t n, size_t col_stride,
+                                                         uint32_t nblk) {
+  __shared__ Fr part[256];
+  const uint32_t col = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
+  const Fr* src = in + (size_t)col * col_stride;
+  Fr* dst = out + (size_t)col * col_stride;
+  const size_t base = (size_t)blk * SCAN_BLOCK + (size_t)t * SCAN_E;
+  Fr m[SCAN_E];
+#pragma unroll
+  for (int i = 0; i < SCAN_E; i++) m[i] = base + i < n ? ld_fr(src + base + i) : Fr::one();
+  Fr tot = m[0];
+#pragma unroll
+  for (int i = 1; i < SCAN_E; i++) tot = mul(tot, m[i]);
+  part[t] = tot;
+  __syncthreads();
+  for (uint32_t d = 1; d < 256; d <<= 1) {  // Hillis-Steele inclusive product scan
+    Fr v = t >= d ? part[t - d] : Fr::one();
+    __syncthreads();
+    if (t >= d) part[t] = mul(v, part[t]);
+    __syncthreads();
+  }
+  Fr pre = t == 0 ? Fr::one() : part[t - 1];
+#pragma unroll
+  for (int i = 0; i < SCAN_E; i++) {
+    if (base + i < n) st_fr(dst + base + i, pre);
+    pre = mul(pre, m[i]);
+  }
+  if (t == 255) st_fr(totals + (size_t)col * nblk + blk, part[255]);
+}
+
+// Per column: totals[b] <- product of the blocks before b; rel[col] <- exclusive prefix at row u
+// (relative to a start value of one), needs the local scan result at u.
+__global__ void scan_blocks_kernel(Fr* totals, const Fr* local, Fr* rel, uint32_t ncols, uint32_t nblk, size_t col_stride,
+                                   size_t u) {
+  const uint32_t col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= ncols) return;
+  Fr* t = totals + (size_t)col * nblk;
+  Fr acc = Fr::one();
+  for (uint32_t b = 0; b < nblk; b++) {
+    Fr v = ld_fr(t + b);
+    st_fr(t + b, acc);
+    acc = mul(acc, v);
+  }
+  if (rel) st_fr(rel + col, mul(ld_fr(t + u / SCAN_BLOCK), ld_fr(local + (size_t)col * col_stride + u)));
+}
+
+// start[0] = 1, start[c] = start[c-1] * rel[c-1]  (permutation sets chain through last_z)
+__global__ void scan_chain_kernel(const Fr* rel, Fr* start, uint32_t ncols) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  Fr acc = Fr::one();
+  for (uint32_t c = 0; c < ncols; c++) {
+    st_fr(start + c, acc);
+    acc = mul(acc, ld_fr(rel + c));
+  }
+}
+
+// z[col][row] = start[col] * totals[col][blk(row)] * local[col][row]   (start may be null = one)
+__global__ __launch_bounds__(256) void scan_apply_kernel(Fr* z, const Fr* totals, const Fr* start, size_t n, size_t col_stride,
+                                                         uint32_t nblk) {
+  const uint32_t col = blockIdx.y;
+  Fr* c = z + (size_t)col * col_stride;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    Fr f = ld_fr(totals + (size_t)col * nblk + i / SCAN_BLOCK);
+    if (start) f = mul(f, ld_fr(start + col));
+    st_fr(c + i, mul(f, ld_fr(c + i)));
+  }
+}
+
+// ------------------------------------------------------------------------------ evaluation
+// out[q] = polys[q](points[q]); lane t sums coefficients t, t+256, ... by Horner in x^256.
+__global__ __launch_bounds__(256) void poly_eval_kernel(const Fr* const* polys, const Fr* points, Fr* out, uint32_t n) {
+  __shared__ Fr red[256];
+  const uint32_t q = blockIdx.x, t = threadIdx.x;
+  const Fr* p = polys[q];
+  const Fr x = ld_fr(points + q);
+  Fr x256 = x;
+#pragma unroll 1
+  for (int i = 0; i < 8; i++) x256 = sqr(x256);
+  Fr s = Fr::zero();
+  if (t < n) {
+    uint32_t top = (n - 1 - t) / 256;  // largest j with t + 256 j < n
+    s = ld_fr(p + t + 256u * top);
+    for (uint32_t j = top; j-- > 0;) s = add(mul(s, x256), ld_fr(p + t + 256u * j));
+    s = mul(s, pow_u64(x, t));
+  }
+  red[t] = s;
+  __syncthreads();
+  for (uint32_t d = 128; d >= 1; d >>= 1) {
+    if (t < d) red[t] = add(red[t], red[t + d]);
+    __syncthreads();
+  }
+  if (t == 0) st_fr(out + q, red[0]);
+}
+
+// ------------------------------------------------------------------------------ linear combinations
+// out[i] = (accumulate ? out[i] : 0) + sum_j coefs[j] * polys[j][i]
+__global__ __launch_bounds__(256) void lincomb_kernel(const Fr* const* polys, const Fr* coefs, uint32_t m, Fr* out, size_t n,
+                                                      int accumulate) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    Fr acc = accumulate ? ld_fr(out + i) : Fr::zero();
+    for (uint32_t j = 0; j < m; j++) acc = add(acc, mul(ld_fr(coefs + j), ld_fr(polys[j] + i)));
+    st_fr(out + i, acc);
+  }
+}
+
+// a[i] = a[i] * c
+__global__ __launch_bounds__(256) void scale_kernel(Fr* a, size_t n, Fr c) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    st_fr(a + i, mul(ld_fr(a + i), c));
+}
+
+// a[i] -= low[i] for i < m   (subtract a low-degree polynomial)
+__global__ void sub_low_kernel(Fr* a, const Fr* low, uint32_t m) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) st_fr(a + i, sub(ld_fr(a + i), ld_fr(low + i)));
+}
+
+// ------------------------------------------------------------------------------ Kate division
+// In place: a(X) of n coefficients -> q(X) = (a(X) - a(b)) / (X - b), n coefficients with q[n-1] = 0.
+// q_i = sum_{j>i} a_j b^(j-i-1): a suffix recurrence, done as chunk Horner + LDS suffix scan + replay.
+// One workgroup per polynomial (grid.x = polynomial), roots[grid.x].
+__global__ __launch_bounds__(1024) void kate_div_kernel(Fr* const* polys, const Fr* roots, uint32_t n) {
+  __shared__ Fr S[1024];
+  const uint32_t t = threadIdx.x, T = blockDim.x;
+  Fr* a = polys[blockIdx.x];
+  const Fr b = ld_fr(roots + blockIdx.x);
+  const uint32_t E = (n + T - 1) / T;
+  const uint32_t s = t * E, e = s + E < n ? s + E : n;
+  Fr acc = Fr::zero();
+  if (s < n) {
+    acc = ld_fr(a + e - 1);
+    for (uint32_t j = e - 1; j-- > s;) acc = add(mul(acc, b), ld_fr(a + j));
+  }
+  S[t] = acc;  // chunk value relative to its own start
+  __syncthreads();
+  Fr pw = pow_u64(b, E);  // b^(E*d) for the current stride d
+  for (uint32_t d = 1; d < T; d <<= 1) {
+    Fr v = t + d < T ? S[t + d] : Fr::zero();
+    __syncthreads();
+    S[t] = add(S[t], mul(pw, v));
+    __syncthreads();
+    pw = sqr(pw);
+  }
+  if (s < n) {
+    Fr prev = t + 1 < T ? S[t + 1] : Fr::zero();  // carry entering this chunk from above
+    // chunks past the end contributed zero, and e may be short of s+E only in the last live chunk
+    for (uint32_t j = e; j-- > s;) {
+      Fr aj = ld_fr(a + j);
+      st_fr(a + j, prev);
+      prev = add(aj, mul(b, prev));
+    }
+  }
+}
+
+// dst[col][row0 + i] = src[col][i], i < cnt   (blinding rows from a packed host upload)
+__global__ void scatter_rows_kernel(Fr* dst, size_t col_stride, size_t row0, const Fr* src, uint32_t cnt, uint32_t ncols) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cnt * ncols) return;
+  uint32_t col = i / cnt, r = i % cnt;
+  st_fr(dst + (size_t)col * col_stride + row0 + r, ld_fr(src + i));
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------ launch wrappers
+int zk_expr_eval(amdzk_ctx* ctx, const ExprArgs& a, uint32_t depth, const char* name) {
+  size_t shmem = (size_t)(depth ? depth : 1) * EXPR_THREADS * sizeof(Fr);
+  if (shmem > 65536) ZK_HIP(ctx, hipFuncSetAttribute((const void*)expr_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  ZK_LAUNCH(ctx, name, expr_eval_kernel, dim3((unsigned)((a.nrows + EXPR_THREADS - 1) / EXPR_THREADS)), dim3(EXPR_THREADS), shmem, a);
+  return AMDZK_OK;
+}
+
+int zk_batch_invert(amdzk_ctx* ctx, Fr* d_a, Fr* d_scratch, size_t total) {
+  const uint32_t chunk = 32;
+  size_t threads = (total + chunk - 1) / chunk;
+  if (total) ZK_LAUNCH(ctx, "batch_invert", batch_invert_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, d_a, d_scratch, total, chunk);
+  return AMDZK_OK;
+}
+
+int zk_mul_elem(amdzk_ctx* ctx, Fr* d_a, const Fr* d_b, size_t total) {
+  unsigned gx = (unsigned)((total + 255) / 256);
+  if (gx > 4096) gx = 4096;
+  if (total) ZK_LAUNCH(ctx, "mul_elem", mul_elem_kernel, dim3(gx), dim3(256), 0, d_a, d_b, total);
+  return AMDZK_OK;
+}
+
+size_t zk_scan_totals_elems(size_t n, size_t ncols) { return ((n + SCAN_BLOCK - 1) / SCAN_BLOCK) * ncols; }
+
+// z[col] = exclusive prefix product of frac[col] (in place), times the chained start value when
+// `chain` (permutation sets: start[c] = z[c-1][u]). d_tmp: totals | rel | start.
+int zk_running_product(amdzk_ctx* ctx, Fr* d_cols, size_t ncols, size_t n, size_t col_stride, bool chain, size_t u, Fr* d_tmp) {
+  if (ncols == 0) return AMDZK_OK;
+  const uint32_t nblk = (uint32_t)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+  Fr* totals = d_tmp;
+  Fr* rel = totals + (size_t)nblk * ncols;
+  Fr* start = rel + ncols;
+  ZK_LAUNCH(ctx, "scan_local", scan_local_kernel, dim3(nblk, (unsigned)ncols), dim3(256), 0, d_cols, d_cols, totals, n, col_stride, nblk);
+  ZK_LAUNCH(ctx, "scan_blocks", scan_blocks_kernel, dim3((unsigned)((ncols + 63) / 64)), dim3(64), 0, totals, d_cols,
+            chain ? rel : (Fr*)nullptr, (uint32_t)ncols, nblk, col_stride, u);
+  if (chain) ZK_LAUNCH(ctx, "scan_chain", scan_chain_kernel, dim3(1), dim3(64), 0, rel, start, (uint32_t)ncols);
+  unsigned gx = (unsigned)((n + 255) / 256);
+  if (gx > 1024) gx = 1024;
+  ZK_LAUNCH(ctx, "scan_apply", scan_apply_kernel, dim3(gx, (unsigned)ncols), dim3(256), 0, d_cols, totals, chain ? start : (const Fr*)nullptr, n,
+            col_stride, nblk);
+  return AMDZK_OK;
+}
+
+int zk_poly_eval(amdzk_ctx* ctx, const Fr* const* d_polys, const Fr* d_points, Fr* d_out, size_t nq, uint32_t n) {
+  if (nq) ZK_LAUNCH(ctx, "poly_eval", poly_eval_kernel, dim3((unsigned)nq), dim3(256), 0, d_polys, d_points, d_out, n);
+  return AMDZK_OK;
+}
+
+int zk_lincomb(amdzk_ctx* ctx, const Fr* const* d_polys, const Fr* d_coefs, uint32_t m, Fr* d_out, size_t n, bool accumulate) {
+  unsigned gx = (unsigned)((n + 255) / 256);
+  if (gx > 2048) gx = 2048;
+  ZK_LAUNCH(ctx, "lincomb", lincomb_kernel, dim3(gx), dim3(256), 0, d_polys, d_coefs, m, d_out, n, accumulate ? 1 : 0);
+  return AMDZK_OK;
+}
+
+int zk_scale(amdzk_ctx* ctx, Fr* d_a, size_t n, const Fr& c) {
+  unsigned gx = (unsigned)((n + 255) / 256);
+  if (gx > 2048) gx = 2048;
+  if (n) ZK_LAUNCH(ctx, "scale", scale_kernel, dim3(gx), dim3(256), 0, d_a, n, c);
+  return AMDZK_OK;
+}
+
+int zk_sub_low(amdzk_ctx* ctx, Fr* d_a, const Fr* d_low, uint32_t m) {
+  if (m) ZK_LAUNCH(ctx, "sub_low", sub_low_kernel, dim3((m + 63) / 64), dim3(64), 0, d_a, d_low, m);
+  return AMDZK_OK;
+}
+
+int zk_kate_div(amdzk_ctx* ctx, Fr* const* d_polys, const Fr* d_roots, size_t npolys, uint32_t n) {
+  unsigned threads = n >= 1024 ? 1024 : (n >= 64 ? (unsigned)(n / 64 * 64 > 1024 ? 1024 : ((n + 63) / 64 * 64)) : 64);
+  if (threads > 1024) threads = 1024;
+  if (npolys) ZK_LAUNCH(ctx, "kate_div", kate_div_kernel, dim3((unsigned)npolys), dim3(threads), 0, d_polys, d_roots, n);
+  return AMDZK_OK;
+}
+
+int zk_scatter_rows(amdzk_ctx* ctx, Fr* d_dst, size_t col_stride, size_t row0, const Fr* d_src, uint32_t cnt, uint32_t ncols) {
+  uint32_t total = cnt * ncols;
+  if (total) ZK_LAUNCH(ctx, "scatter_rows", scatter_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, d_dst, col_stride, row0, d_src, cnt, ncols);
+  return AMDZK_OK;
+}

@@ -1,0 +1,1282 @@
+// Prover driver: keygen_pk and create_proof for KZG + SHPLONK + Blake2b, one circuit instance,
+// phase 0 — halo2_proofs 0.2.0 @ PSE v2023_01_20 [UP] (/root/reference/Cargo.lock:469-471):
+//   plonk::keygen::{keygen_vk, keygen_pk}, plonk::prover::create_proof,
+//   plonk::{permutation,lookup,vanishing}::prover, poly::kzg::multiopen::shplonk::ProverSHPLONK.
+// This is the function the reference's circuits are handed to; the circuit itself
+// arrives as a plain-data description of its ConstraintSystem (amdzk_circuit) plus its fixed
+// columns, copy-constraint mapping and witness columns. The order of transcript operations and RNG
+// draws follows SURVEY.md Appendix A.
+//
+// Control flow, Fiat-Shamir and the O(columns) bookkeeping stay on the host; every O(n) step is a
+// kernel on resident columns: all committed columns of a phase go through ONE batched MSM, all
+// polynomials through ONE batched iNTT and ONE batched coset NTT, and the whole h(X) numerator is
+// ONE interpreter launch. Host<->device traffic per proof: the blinding scalars and the random
+// polynomial up (n*32 B), commitments and evaluations down — except the lookup permutation, which
+// round 1 still does on the host (next row).
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <array>
+#include <thread>
+
+#include "hostcrypto.hpp"
+#include "plonk_kernels.hpp"
+
+using namespace bn254;
+using zkhost::Blake2bWrite;
+using zkhost::ChaCha20Rng;
+
+// from the other translation units
+struct amdzk_srs;
+struct amdzk_domain;
+int zk_msm_dev_xyzz(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const Fr* d_scalars, size_t ncols, size_t len, size_t col_stride,
+                    G1X** d_out);
+int zk_msm_finish(amdzk_ctx* ctx, const G1X* d_res, size_t ncols, uint64_t* out_jac);
+extern "C" {
+int amdzk_domain_new(amdzk_ctx* ctx, uint32_t j, uint32_t k, amdzk_domain** out);
+void amdzk_domain_free(amdzk_ctx* ctx, amdzk_domain* d);
+uint32_t amdzk_domain_extended_k(const amdzk_domain* d);
+int amdzk_domain_constant(const amdzk_domain* d, int what, uint64_t out[4]);
+int amdzk_lagrange_to_coeff_dev(amdzk_ctx* ctx, const amdzk_domain* d, void* d_cols, size_t ncols, size_t col_stride);
+int amdzk_coeff_to_extended_dev(amdzk_ctx* ctx, const amdzk_domain* d, const void* d_coeff, size_t in_stride, void* d_ext, size_t out_stride,
+                                size_t ncols);
+int amdzk_extended_to_coeff_dev(amdzk_ctx* ctx, const amdzk_domain* d, void* d_ext, size_t ncols, size_t col_stride);
+int amdzk_divide_by_vanishing_dev(amdzk_ctx* ctx, const amdzk_domain* d, void* d_ext, size_t ncols, size_t col_stride);
+int amdzk_fr_to_repr_dev(amdzk_ctx* ctx, void* d_a, size_t n);
+int amdzk_fr_from_raw_dev(amdzk_ctx* ctx, void* d_a, size_t n);
+}
+
+namespace {
+
+// host-format expression words (include/amdzk.h)
+enum : uint32_t { XOP_CONST = 1, XOP_FIXED = 2, XOP_ADVICE = 3, XOP_INSTANCE = 4, XOP_NEG = 5, XOP_ADD = 6, XOP_MUL = 7, XOP_SCALE = 8 };
+
+Fr fr_delta() {  // Fr::DELTA = 7^(2^28)  (contract.sol:440)
+  Fr r;
+  uint64_t v[4] = {0x870e56bbe533e9a2ULL, 0x5b5f898e5e963f25ULL, 0x64ec26aad4c86e71ULL, 0x09226b6e22c6f0caULL};
+  memcpy(r.l, v, 32);
+  return to_mont(r);
+}
+
+struct Program {
+  std::vector<uint32_t> words;
+  uint32_t depth = 0, cur = 0;
+  uint32_t* d_words = nullptr;
+  void op(uint32_t o, uint32_t arg = 0) { words.push_back((o << 24) | (arg & 0xffffffu)); }
+  void push() {
+    cur++;
+    if (cur > depth) depth = cur;
+  }
+  void pop() { cur--; }
+};
+
+struct RotTable {
+  std::vector<int32_t> rots;
+  uint32_t index(int32_t r) {
+    for (size_t i = 0; i < rots.size(); i++)
+      if (rots[i] == r) return (uint32_t)i;
+    rots.push_back(r);
+    return (uint32_t)rots.size() - 1;
+  }
+};
+
+bool fr_less_canon(const std::array<uint64_t, 4>& a, const std::array<uint64_t, 4>& b) {
+  for (int i = 3; i >= 0; i--)
+    if (a[i] != b[i]) return a[i] < b[i];
+  return false;
+}
+std::array<uint64_t, 4> canon(const Fr& a) {
+  Fr c = from_mont(a);
+  std::array<uint64_t, 4> o;
+  memcpy(o.data(), c.l, 32);
+  return o;
+}
+
+}  // namespace
+
+struct amdzk_pk {
+  uint32_t k = 0, ek = 0, bf = 0, degree = 0, F = 0, A = 0, I = 0, S = 0, L = 0, nsets = 0, chunk = 0, qdeg = 0;
+  size_t n = 0, ext = 0;
+  std::vector<std::pair<int, int>> advice_queries, fixed_queries, instance_queries;
+  std::vector<std::pair<int, int>> perm_cols;  // (kind, index)
+  std::vector<std::vector<uint32_t>> exprs;
+  uint32_t num_gates = 0;
+  std::vector<std::pair<uint32_t, uint32_t>> lookup_shape;  // (#inputs, #tables); expressions follow the gates in order
+  std::vector<Fr> consts;                                   // circuit constants, then the dynamic ones
+  uint32_t c_one = 0, c_theta = 0, c_beta = 0, c_gamma = 0, c_y = 0, c_bdelta = 0;
+  amdzk_domain* dom = nullptr;
+  const amdzk_srs* srs = nullptr;
+  Fr transcript_repr, omega, omega_inv;
+  std::vector<G1Affine> fixed_commitments, perm_commitments;
+
+  // device: key material
+  Fr *fixed_lag = nullptr, *fixed_poly = nullptr, *fixed_coset = nullptr;
+  Fr *sigma_lag = nullptr, *sigma_poly = nullptr, *sigma_coset = nullptr;
+  Fr *l0_c = nullptr, *llast_c = nullptr, *lactive_c = nullptr, *x_coset = nullptr, *omega_pow = nullptr;
+  // device: per-proof workspace. poly arena order: adv | inst | la | ls | zp | zl
+  size_t NP = 0;
+  Fr *P = nullptr, *PC = nullptr;   // [NP][n], [NP][ext]
+  Fr *ci = nullptr, *ct = nullptr;  // [L][n] compressed lookup input / table
+  Fr *rnd = nullptr, *hq = nullptr, *hpoly = nullptr, *frac = nullptr, *scratch = nullptr, *scan_tmp = nullptr;
+  Fr *sets_L = nullptr, *sets_N = nullptr, *hx = nullptr;  // SHPLONK buffers
+  Fr* small = nullptr;  // misc small device buffer (blinding uploads, points, evals, coefs)
+  void* ptrs = nullptr;  // device pointer-table scratch
+  size_t small_cap = 0, ptrs_cap = 0;
+  // programs
+  Program prog_compress, prog_pfrac, prog_lfrac, prog_h;
+  RotTable rots;
+  int32_t *d_rot_lag = nullptr, *d_rot_ext = nullptr;
+  Fr* d_consts = nullptr;
+  const Fr** d_cols_lag = nullptr;
+  const Fr** d_cols_ext = nullptr;
+  Fr** d_outs_compress = nullptr;
+  Fr** d_outs_pfrac = nullptr;
+  Fr** d_outs_lfrac = nullptr;
+  std::vector<void*> allocs;
+
+  Fr* adv() { return P; }
+  Fr* inst() { return P + (size_t)A * n; }
+  Fr* la() { return P + (size_t)(A + I) * n; }
+  Fr* ls() { return P + (size_t)(A + I + L) * n; }
+  Fr* zp() { return P + (size_t)(A + I + 2 * L) * n; }
+  Fr* zl() { return P + (size_t)(A + I + 2 * L + nsets) * n; }
+  // slots, Lagrange table
+  uint32_t sl_fixed(uint32_t c) { return c; }
+  uint32_t sl_adv(uint32_t c) { return F + c; }
+  uint32_t sl_inst(uint32_t c) { return F + A + c; }
+  uint32_t sl_sigma(uint32_t c) { return F + A + I + c; }
+  uint32_t sl_ci(uint32_t l) { return F + A + I + S + l; }
+  uint32_t sl_ct(uint32_t l) { return F + A + I + S + L + l; }
+  uint32_t sl_la(uint32_t l) { return F + A + I + S + 2 * L + l; }
+  uint32_t sl_ls(uint32_t l) { return F + A + I + S + 3 * L + l; }
+  uint32_t sl_omega() { return F + A + I + S + 4 * L; }
+  uint32_t nslots_lag() { return F + A + I + S + 4 * L + 1; }
+  // slots, extended table
+  uint32_t se_sigma(uint32_t c) { return F + A + I + c; }
+  uint32_t se_zp(uint32_t s) { return F + A + I + S + s; }
+  uint32_t se_zl(uint32_t l) { return F + A + I + S + nsets + l; }
+  uint32_t se_la(uint32_t l) { return F + A + I + S + nsets + L + l; }
+  uint32_t se_ls(uint32_t l) { return F + A + I + S + nsets + 2 * L + l; }
+  uint32_t se_l0() { return F + A + I + S + nsets + 3 * L; }
+  uint32_t se_llast() { return se_l0() + 1; }
+  uint32_t se_lactive() { return se_l0() + 2; }
+  uint32_t se_x() { return se_l0() + 3; }
+  uint32_t nslots_ext() { return se_l0() + 4; }
+};
+
+namespace {
+
+template <class T>
+int dalloc(amdzk_ctx* ctx, amdzk_pk* pk, T** p, size_t count) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, (count ? count : 1) * sizeof(T));
+  if (e != hipSuccess) ZK_FAIL(ctx, AMDZK_E_NOMEM, "prover: hipMalloc(%zu) failed: %s", count * sizeof(T), hipGetErrorString(e));
+  pk->allocs.push_back(q);
+  *p = (T*)q;
+  return AMDZK_OK;
+}
+
+int h2d(amdzk_ctx* ctx, void* d, const void* h, size_t bytes) {
+  if (bytes) ZK_HIP(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return AMDZK_OK;
+}
+int d2h(amdzk_ctx* ctx, void* h, const void* d, size_t bytes) {
+  if (bytes) {
+    ZK_HIP(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return AMDZK_OK;
+}
+int d2d(amdzk_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (bytes) ZK_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return AMDZK_OK;
+}
+
+// MSM of ncols resident columns -> affine points on the host
+int commit_cols(amdzk_ctx* ctx, amdzk_pk* pk, int basis, const Fr* d_cols, size_t ncols, std::vector<G1Affine>& out) {
+  out.resize(ncols);
+  if (ncols == 0) return AMDZK_OK;
+  G1X* d_res = nullptr;
+  ZK_TRY(zk_msm_dev_xyzz(ctx, pk->srs, basis, d_cols, ncols, pk->n, pk->n, &d_res));
+  std::vector<uint64_t> jac(12 * ncols);
+  ZK_TRY(zk_msm_finish(ctx, d_res, ncols, jac.data()));
+  for (size_t i = 0; i < ncols; i++) {
+    const G1Jac* j = reinterpret_cast<const G1Jac*>(&jac[12 * i]);
+    if (j->z.is_zero()) {
+      out[i].x = Fq::zero();
+      out[i].y = Fq::zero();
+    } else {
+      out[i].x = j->x;
+      out[i].y = j->y;
+    }
+  }
+  return AMDZK_OK;
+}
+
+// translate a host-format postfix expression into device ops; Lagrange and extended programs share
+// slot numbers for fixed/advice/instance columns.
+int emit_expr(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, const std::vector<uint32_t>& words) {
+  for (uint32_t w : words) {
+    uint32_t op = w >> 24, pl = w & 0xffffffu;
+    switch (op) {
+      case XOP_CONST:
+        if (pl >= pk->c_one) ZK_FAIL(ctx, AMDZK_E_INVALID, "circuit: constant index %u out of range", pl);
+        pr.op(OP_PUSH_CONST, pl);
+        pr.push();
+        break;
+      case XOP_FIXED:
+      case XOP_ADVICE:
+      case XOP_INSTANCE: {
+        uint32_t col = pl >> 8;
+        int32_t rot = (int32_t)(pl & 0xff) - 128;
+        uint32_t lim = op == XOP_FIXED ? pk->F : op == XOP_ADVICE ? pk->A : pk->I;
+        if (col >= lim) ZK_FAIL(ctx, AMDZK_E_INVALID, "circuit: column %u out of range", col);
+        uint32_t slot = op == XOP_FIXED ? pk->sl_fixed(col) : op == XOP_ADVICE ? pk->sl_adv(col) : pk->sl_inst(col);
+        pr.op(OP_PUSH_COL, (slot << 8) | pk->rots.index(rot));
+        pr.push();
+      } break;
+      case XOP_NEG:
+        pr.op(OP_NEG);
+        break;
+      case XOP_ADD:
+        pr.op(OP_ADD);
+        pr.pop();
+        break;
+      case XOP_MUL:
+        pr.op(OP_MUL);
+        pr.pop();
+        break;
+      case XOP_SCALE:
+        if (pl >= pk->c_one) ZK_FAIL(ctx, AMDZK_E_INVALID, "circuit: constant index %u out of range", pl);
+        pr.op(OP_MUL_CONST, pl);
+        break;
+      default:
+        ZK_FAIL(ctx, AMDZK_E_INVALID, "circuit: bad expression word %08x", w);
+    }
+  }
+  return AMDZK_OK;
+}
+
+// fold(acc * theta + expr) over a lookup's expressions (first term: 0*theta + e0 = e0)
+int emit_compressed(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, uint32_t first, uint32_t count) {
+  for (uint32_t i = 0; i < count; i++) {
+    if (i > 0) pr.op(OP_MUL_CONST, pk->c_theta);
+    ZK_TRY(emit_expr(ctx, pk, pr, pk->exprs[first + i]));
+    if (i > 0) {
+      pr.op(OP_ADD);
+      pr.pop();
+    }
+  }
+  return AMDZK_OK;
+}
+
+int upload_program(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr) {
+  ZK_TRY(dalloc(ctx, pk, &pr.d_words, pr.words.size()));
+  return h2d(ctx, pr.d_words, pr.words.data(), pr.words.size() * 4);
+}
+
+int run_program(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, bool extended, Fr* const* d_outs, Fr* h_out, const char* name) {
+  ExprArgs a;
+  a.prog = pr.d_words;
+  a.prog_len = (uint32_t)pr.words.size();
+  a.cols = extended ? pk->d_cols_ext : pk->d_cols_lag;
+  a.consts = pk->d_consts;
+  a.rot_off = extended ? pk->d_rot_ext : pk->d_rot_lag;
+  a.outs = d_outs;
+  a.h_out = h_out;
+  a.nrows = extended ? pk->ext : pk->n;
+  a.mask = a.nrows - 1;
+  a.y_const = pk->c_y;
+  return zk_expr_eval(ctx, a, pr.depth + 1, name);
+}
+
+Fr rotate_omega(const amdzk_pk* pk, const Fr& x, int rot) {
+  return rot >= 0 ? mul(x, pow_u64(pk->omega, (uint64_t)rot)) : mul(x, pow_u64(pk->omega_inv, (uint64_t)(-rot)));
+}
+
+// arithmetic::lagrange_interpolate: coefficients of the polynomial of degree < m through (points, evals)
+std::vector<Fr> lagrange_interpolate(const std::vector<Fr>& pts, const std::vector<Fr>& evals) {
+  size_t m = pts.size();
+  std::vector<Fr> out(m, Fr::zero());
+  for (size_t j = 0; j < m; j++) {
+    std::vector<Fr> num(1, Fr::one());
+    Fr den = Fr::one();
+    for (size_t k2 = 0; k2 < m; k2++) {
+      if (k2 == j) continue;
+      num.insert(num.begin(), Fr::zero());
+      for (size_t t = 0; t + 1 < num.size(); t++) num[t] = sub(num[t], mul(pts[k2], num[t + 1]));
+      den = mul(den, sub(pts[j], pts[k2]));
+    }
+    Fr sc = mul(evals[j], inv(den));
+    for (size_t t = 0; t < num.size(); t++) out[t] = add(out[t], mul(num[t], sc));
+  }
+  return out;
+}
+Fr eval_small(const std::vector<Fr>& poly, const Fr& x) {
+  Fr acc = Fr::zero();
+  for (size_t i = poly.size(); i-- > 0;) acc = add(mul(acc, x), poly[i]);
+  return acc;
+}
+
+void trace_fr(const char* label, const Fr& v) {
+  if (!getenv("AMDZK_TRACE")) return;
+  uint8_t b[32];
+  zkhost::fr_to_repr(v, b);
+  fprintf(stderr, "[amdzk] %s ", label);
+  for (int i = 31; i >= 0; i--) fprintf(stderr, "%02x", b[i]);
+  fprintf(stderr, "\n");
+}
+void trace_pt(const char* label, const G1Affine& p) {
+  if (!getenv("AMDZK_TRACE")) return;
+  uint8_t b[32];
+  zkhost::fq_to_repr(p.x, b);
+  fprintf(stderr, "[amdzk] %s x=", label);
+  for (int i = 31; i >= 0; i--) fprintf(stderr, "%02x", b[i]);
+  fprintf(stderr, "\n");
+}
+
+// lookup::prover::permute_expression_pair on canonical values (host, one lookup)
+bool permute_pair(const std::array<uint64_t, 4>* inp, const std::array<uint64_t, 4>* tab, size_t usable, std::array<uint64_t, 4>* out_a,
+                  std::array<uint64_t, 4>* out_s) {
+  std::vector<std::array<uint64_t, 4>> a(inp, inp + usable), t(tab, tab + usable);
+  std::sort(a.begin(), a.end(), fr_less_canon);
+  std::sort(t.begin(), t.end(), fr_less_canon);
+  std::vector<uint8_t> used(usable, 0);
+  std::vector<size_t> repeated;
+  size_t tp = 0;
+  for (size_t row = 0; row < usable; row++) {
+    out_a[row] = a[row];
+    if (row == 0 || a[row] != a[row - 1]) {
+      while (tp < usable && fr_less_canon(t[tp], a[row])) tp++;
+      if (tp >= usable || t[tp] != a[row]) return false;  // input value not in the table
+      used[tp] = 1;
+      out_s[row] = a[row];
+      tp++;  // later distinct inputs are larger; duplicates of this value stay unmarked (leftovers)
+    } else {
+      repeated.push_back(row);
+    }
+  }
+  for (size_t i = 0; i < usable; i++) {  // leftovers ascending -> repeated rows from the back
+    if (used[i]) continue;
+    if (repeated.empty()) return false;
+    out_s[repeated.back()] = t[i];
+    repeated.pop_back();
+  }
+  return repeated.empty();
+}
+
+}  // namespace
+
+extern "C" {
+
+void amdzk_pk_free(amdzk_ctx* ctx, amdzk_pk* pk) {
+  if (!pk) return;
+  if (ctx) hipStreamSynchronize(ctx->stream);
+  for (void* p : pk->allocs) hipFree(p);
+  if (pk->dom) amdzk_domain_free(ctx, pk->dom);
+  delete pk;
+}
+
+int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, const uint64_t* fixed_values, const uint32_t* perm_mapping,
+                 const uint64_t transcript_repr[4], amdzk_pk** out) {
+  if (!ctx) return AMDZK_E_INVALID;
+  if (!srs || !c || !out || !transcript_repr) ZK_FAIL(ctx, AMDZK_E_INVALID, "keygen: null argument");
+  if (c->cs_degree < 3) ZK_FAIL(ctx, AMDZK_E_INVALID, "keygen: cs_degree %u < 3", c->cs_degree);
+  amdzk_pk* pk = new amdzk_pk();
+#define KG_TRY(x)                  \
+  do {                             \
+    int _r = (x);                  \
+    if (_r != AMDZK_OK) {          \
+      amdzk_pk_free(ctx, pk);      \
+      return _r;                   \
+    }                              \
+  } while (0)
+  pk->srs = srs;
+  pk->k = c->k;
+  pk->n = (size_t)1 << c->k;
+  pk->bf = c->blinding_factors;
+  pk->degree = c->cs_degree;
+  pk->F = c->num_fixed;
+  pk->A = c->num_advice;
+  pk->I = c->num_instance;
+  pk->S = c->num_perm_columns;
+  pk->L = c->num_lookups;
+  pk->chunk = pk->degree - 2;
+  pk->nsets = (pk->S + pk->chunk - 1) / pk->chunk;
+  pk->qdeg = pk->degree - 1;
+  if (pk->n < pk->bf + 3) {
+    amdzk_pk_free(ctx, pk);
+    ZK_FAIL(ctx, AMDZK_E_INVALID, "keygen: not enough rows (n = %zu, blinding factors = %u)", pk->n, pk->bf);
+  }
+  memcpy(pk->transcript_repr.l, transcript_repr, 32);
+  KG_TRY(amdzk_domain_new(ctx, pk->degree, pk->k, &pk->dom));
+  pk->ek = amdzk_domain_extended_k(pk->dom);
+  pk->ext = (size_t)1 << pk->ek;
+  amdzk_domain_constant(pk->dom, 0, (uint64_t*)pk->omega.l);
+  amdzk_domain_constant(pk->dom, 1, (uint64_t*)pk->omega_inv.l);
+  Fr ext_omega, zeta;
+  amdzk_domain_constant(pk->dom, 2, (uint64_t*)ext_omega.l);
+  amdzk_domain_constant(pk->dom, 4, (uint64_t*)zeta.l);
+  for (uint32_t i = 0; i < c->num_advice_queries; i++) pk->advice_queries.push_back({c->advice_queries[2 * i], c->advice_queries[2 * i + 1]});
+  for (uint32_t i = 0; i < c->num_fixed_queries; i++) pk->fixed_queries.push_back({c->fixed_queries[2 * i], c->fixed_queries[2 * i + 1]});
+  for (uint32_t i = 0; i < c->num_instance_queries; i++)
+    pk->instance_queries.push_back({c->instance_queries[2 * i], c->instance_queries[2 * i + 1]});
+  for (uint32_t i = 0; i < pk->S; i++) pk->perm_cols.push_back({(int)c->perm_columns[2 * i], (int)c->perm_columns[2 * i + 1]});
+  pk->num_gates = c->num_gates;
+  uint32_t nexpr = c->num_gates;
+  for (uint32_t l = 0; l < pk->L; l++) {
+    pk->lookup_shape.push_back({c->lookup_shape[2 * l], c->lookup_shape[2 * l + 1]});
+    nexpr += c->lookup_shape[2 * l] + c->lookup_shape[2 * l + 1];
+  }
+  if (nexpr != c->num_exprs) {
+    amdzk_pk_free(ctx, pk);
+    ZK_FAIL(ctx, AMDZK_E_INVALID, "keygen: expression count mismatch (%u vs %u)", nexpr, c->num_exprs);
+  }
+  for (uint32_t e = 0; e < c->num_exprs; e++)
+    pk->exprs.emplace_back(c->expr_words + c->expr_offsets[e], c->expr_words + c->expr_offsets[e + 1]);
+  // constants: circuit | one theta beta gamma y | beta*delta^j (j < S)
+  pk->consts.resize(c->num_constants);
+  if (c->num_constants) memcpy(pk->consts.data(), c->constants, (size_t)c->num_constants * 32);
+  pk->c_one = c->num_constants;
+  pk->c_theta = pk->c_one + 1;
+  pk->c_beta = pk->c_one + 2;
+  pk->c_gamma = pk->c_one + 3;
+  pk->c_y = pk->c_one + 4;
+  pk->c_bdelta = pk->c_one + 5;
+  pk->consts.resize(pk->c_bdelta + pk->S, Fr::zero());
+  pk->consts[pk->c_one] = Fr::one();
+
+  const size_t n = pk->n, ext = pk->ext;
+  const uint32_t F = pk->F, A = pk->A, I = pk->I, S = pk->S, L = pk->L, ns = pk->nsets;
+  // ---- device allocations
+  KG_TRY(dalloc(ctx, pk, &pk->fixed_lag, (size_t)F * n));
+  KG_TRY(dalloc(ctx, pk, &pk->fixed_poly, (size_t)F * n));
+  KG_TRY(dalloc(ctx, pk, &pk->fixed_coset, (size_t)F * ext));
+  KG_TRY(dalloc(ctx, pk, &pk->sigma_lag, (size_t)S * n));
+  KG_TRY(dalloc(ctx, pk, &pk->sigma_poly, (size_t)S * n));
+  KG_TRY(dalloc(ctx, pk, &pk->sigma_coset, (size_t)S * ext));
+  KG_TRY(dalloc(ctx, pk, &pk->l0_c, ext));
+  KG_TRY(dalloc(ctx, pk, &pk->llast_c, ext));
+  KG_TRY(dalloc(ctx, pk, &pk->lactive_c, ext));
+  KG_TRY(dalloc(ctx, pk, &pk->x_coset, ext));
+  KG_TRY(dalloc(ctx, pk, &pk->omega_pow, n));
+  pk->NP = (size_t)A + I + 2 * L + ns + L;
+  KG_TRY(dalloc(ctx, pk, &pk->P, pk->NP * n));
+  KG_TRY(dalloc(ctx, pk, &pk->PC, pk->NP * ext));
+  KG_TRY(dalloc(ctx, pk, &pk->ci, (size_t)L * n));
+  KG_TRY(dalloc(ctx, pk, &pk->ct, (size_t)L * n));
+  KG_TRY(dalloc(ctx, pk, &pk->rnd, n));
+  KG_TRY(dalloc(ctx, pk, &pk->hq, ext));
+  KG_TRY(dalloc(ctx, pk, &pk->hpoly, n));
+  const size_t nfrac = std::max<size_t>(std::max<size_t>(ns, L), 1);
+  KG_TRY(dalloc(ctx, pk, &pk->frac, nfrac * n));
+  KG_TRY(dalloc(ctx, pk, &pk->scratch, std::max(nfrac * n, ext)));
+  KG_TRY(dalloc(ctx, pk, &pk->scan_tmp, zk_scan_totals_elems(n, nfrac) + 2 * nfrac + 8));
+  const size_t max_rsets = 16;
+  KG_TRY(dalloc(ctx, pk, &pk->sets_L, max_rsets * n));
+  KG_TRY(dalloc(ctx, pk, &pk->sets_N, max_rsets * n));
+  KG_TRY(dalloc(ctx, pk, &pk->hx, n));
+  pk->small_cap = std::max<size_t>((size_t)pk->NP * (pk->bf + 2) + 4096, 8192);
+  KG_TRY(dalloc(ctx, pk, &pk->small, pk->small_cap));
+  pk->ptrs_cap = 8192;
+  {
+    void** pp = nullptr;
+    KG_TRY(dalloc(ctx, pk, &pp, pk->ptrs_cap));
+    pk->ptrs = pp;
+  }
+
+  // ---- host-side tables: omega powers, coset points, l0 / l_last / l_blind (Lagrange)
+  {
+    std::vector<Fr> op(n), l0(n, Fr::zero()), ll(n, Fr::zero()), lb(n, Fr::zero());
+    Fr cur = Fr::one();
+    for (size_t i = 0; i < n; i++) {
+      op[i] = cur;
+      cur = mul(cur, pk->omega);
+    }
+    KG_TRY(h2d(ctx, pk->omega_pow, op.data(), n * 32));
+    l0[0] = Fr::one();
+    ll[n - pk->bf - 1] = Fr::one();
+    for (size_t i = n - pk->bf; i < n; i++) lb[i] = Fr::one();
+    // to cosets via the same device path as every other polynomial: pack [l0 | l_last | l_blind] into hq-sized temp
+    Fr* tmp = pk->scratch;  // >= ext >= 3n? ext >= 2n only when degree >= 4; use three separate passes
+    Fr* dst[3] = {pk->l0_c, pk->llast_c, pk->lactive_c};
+    std::vector<Fr>* src[3] = {&l0, &ll, &lb};
+    for (int t = 0; t < 3; t++) {
+      KG_TRY(h2d(ctx, tmp, src[t]->data(), n * 32));
+      KG_TRY(amdzk_lagrange_to_coeff_dev(ctx, pk->dom, tmp, 1, n));
+      KG_TRY(amdzk_coeff_to_extended_dev(ctx, pk->dom, tmp, n, dst[t], ext, 1));
+      ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    std::vector<Fr> xc(ext);
+    cur = zeta;
+    for (size_t i = 0; i < ext; i++) {
+      xc[i] = cur;
+      cur = mul(cur, ext_omega);
+    }
+    KG_TRY(h2d(ctx, pk->x_coset, xc.data(), ext * 32));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  // ---- fixed columns and permutation polynomials
+  if (F) {
+    if (!fixed_values) {
+      amdzk_pk_free(ctx, pk);
+      ZK_FAIL(ctx, AMDZK_E_INVALID, "keygen: fixed_values is null");
+    }
+    KG_TRY(h2d(ctx, pk->fixed_lag, fixed_values, (size_t)F * n * 32));
+    KG_TRY(d2d(ctx, pk->fixed_poly, pk->fixed_lag, (size_t)F * n * 32));
+    KG_TRY(amdzk_lagrange_to_coeff_dev(ctx, pk->dom, pk->fixed_poly, F, n));
+    KG_TRY(amdzk_coeff_to_extended_dev(ctx, pk->dom, pk->fixed_poly, n, pk->fixed_coset, ext, F));
+    KG_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G_LAGRANGE, pk->fixed_lag, F, pk->fixed_commitments));
+  }
+  if (S) {
+    if (!perm_mapping) {
+      amdzk_pk_free(ctx, pk);
+      ZK_FAIL(ctx, AMDZK_E_INVALID, "keygen: perm_mapping is null");
+    }
+    // sigma_i(omega^j) = delta^(i') * omega^(j'), (i', j') = mapping[i][j]
+    std::vector<Fr> dpow(S), op(n), sig((size_t)S * n);
+    Fr delta = fr_delta(), cur = Fr::one();
+    for (uint32_t i = 0; i < S; i++) {
+      dpow[i] = cur;
+      cur = mul(cur, delta);
+    }
+    cur = Fr::one();
+    for (size_t i = 0; i < n; i++) {
+      op[i] = cur;
+      cur = mul(cur, pk->omega);
+    }
+    for (uint32_t i = 0; i < S; i++)
+      for (size_t j = 0; j < n; j++) {
+        uint32_t pi = perm_mapping[2 * ((size_t)i * n + j)], pj = perm_mapping[2 * ((size_t)i * n + j) + 1];
+        if (pi >= S || pj >= n) {
+          amdzk_pk_free(ctx, pk);
+          ZK_FAIL(ctx, AMDZK_E_INVALID, "keygen: permutation mapping out of range");
+        }
+        sig[(size_t)i * n + j] = mul(dpow[pi], op[pj]);
+      }
+    KG_TRY(h2d(ctx, pk->sigma_lag, sig.data(), (size_t)S * n * 32));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    KG_TRY(d2d(ctx, pk->sigma_poly, pk->sigma_lag, (size_t)S * n * 32));
+    KG_TRY(amdzk_lagrange_to_coeff_dev(ctx, pk->dom, pk->sigma_poly, S, n));
+    KG_TRY(amdzk_coeff_to_extended_dev(ctx, pk->dom, pk->sigma_poly, n, pk->sigma_coset, ext, S));
+    KG_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G_LAGRANGE, pk->sigma_lag, S, pk->perm_commitments));
+  }
+  // l_active = 1 - (l_last + l_blind) on the coset: lactive_c currently holds l_blind's coset
+  {
+    // prog: one - l_last - l_blind, stored into lactive_c. Done with a tiny dedicated program below, after tables exist.
+  }
+
+  // ---- column pointer tables
+  {
+    std::vector<const Fr*> lag(pk->nslots_lag()), ex(pk->nslots_ext());
+    for (uint32_t i = 0; i < F; i++) lag[pk->sl_fixed(i)] = pk->fixed_lag + (size_t)i * n, ex[i] = pk->fixed_coset + (size_t)i * ext;
+    for (uint32_t i = 0; i < A; i++) lag[pk->sl_adv(i)] = pk->adv() + (size_t)i * n, ex[pk->sl_adv(i)] = pk->PC + (size_t)i * ext;
+    for (uint32_t i = 0; i < I; i++) lag[pk->sl_inst(i)] = pk->inst() + (size_t)i * n, ex[pk->sl_inst(i)] = pk->PC + (size_t)(A + i) * ext;
+    for (uint32_t i = 0; i < S; i++) lag[pk->sl_sigma(i)] = pk->sigma_lag + (size_t)i * n, ex[pk->se_sigma(i)] = pk->sigma_coset + (size_t)i * ext;
+    for (uint32_t l = 0; l < L; l++) {
+      lag[pk->sl_ci(l)] = pk->ci + (size_t)l * n;
+      lag[pk->sl_ct(l)] = pk->ct + (size_t)l * n;
+      lag[pk->sl_la(l)] = pk->la() + (size_t)l * n;
+      lag[pk->sl_ls(l)] = pk->ls() + (size_t)l * n;
+      ex[pk->se_la(l)] = pk->PC + (size_t)(A + I + l) * ext;
+      ex[pk->se_ls(l)] = pk->PC + (size_t)(A + I + L + l) * ext;
+      ex[pk->se_zl(l)] = pk->PC + (size_t)(A + I + 2 * L + ns + l) * ext;
+    }
+    for (uint32_t s = 0; s < ns; s++) ex[pk->se_zp(s)] = pk->PC + (size_t)(A + I + 2 * L + s) * ext;
+    lag[pk->sl_omega()] = pk->omega_pow;
+    ex[pk->se_l0()] = pk->l0_c;
+    ex[pk->se_llast()] = pk->llast_c;
+    ex[pk->se_lactive()] = pk->lactive_c;
+    ex[pk->se_x()] = pk->x_coset;
+    KG_TRY(dalloc(ctx, pk, &pk->d_cols_lag, lag.size()));
+    KG_TRY(dalloc(ctx, pk, &pk->d_cols_ext, ex.size()));
+    KG_TRY(h2d(ctx, pk->d_cols_lag, lag.data(), lag.size() * sizeof(Fr*)));
+    KG_TRY(h2d(ctx, pk->d_cols_ext, ex.data(), ex.size() * sizeof(Fr*)));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+
+  // ---- programs
+  auto colkind_slot_lag = [&](std::pair<int, int> kc) { return kc.first == 0 ? pk->sl_adv(kc.second) : kc.first == 1 ? pk->sl_fixed(kc.second) : pk->sl_inst(kc.second); };
+  const uint32_t r0 = pk->rots.index(0), r1 = pk->rots.index(1), rm1 = pk->rots.index(-1), rlast = pk->rots.index(-(int32_t)(pk->bf + 1));
+  auto COL = [&](uint32_t slot, uint32_t r) { return (slot << 8) | r; };
+  // (1) lookup compression: ci[l], ct[l]
+  {
+    Program& pr = pk->prog_compress;
+    uint32_t e = pk->num_gates;
+    for (uint32_t l = 0; l < L; l++) {
+      KG_TRY(emit_compressed(ctx, pk, pr, e, pk->lookup_shape[l].first));
+      pr.op(OP_STORE, 2 * l);
+      pr.pop();
+      e += pk->lookup_shape[l].first;
+      KG_TRY(emit_compressed(ctx, pk, pr, e, pk->lookup_shape[l].second));
+      pr.op(OP_STORE, 2 * l + 1);
+      pr.pop();
+      e += pk->lookup_shape[l].second;
+    }
+    std::vector<Fr*> outs(2 * L);
+    for (uint32_t l = 0; l < L; l++) outs[2 * l] = pk->ci + (size_t)l * n, outs[2 * l + 1] = pk->ct + (size_t)l * n;
+    KG_TRY(dalloc(ctx, pk, &pk->d_outs_compress, outs.size()));
+    KG_TRY(h2d(ctx, pk->d_outs_compress, outs.data(), outs.size() * sizeof(Fr*)));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  // (2) permutation fractions: den[s] -> scratch column s (inverted later), num[s] -> frac column s
+  {
+    Program& pr = pk->prog_pfrac;
+    for (uint32_t s = 0; s < ns; s++) {
+      uint32_t lo = s * pk->chunk, hi = std::min(S, lo + pk->chunk);
+      for (uint32_t j = lo; j < hi; j++) {  // denominator: prod (v + beta*sigma + gamma)
+        pr.op(OP_PUSH_COL, COL(pk->sl_sigma(j), r0));
+        pr.push();
+        pr.op(OP_MUL_CONST, pk->c_beta);
+        pr.op(OP_ADD_COL, COL(colkind_slot_lag(pk->perm_cols[j]), r0));
+        pr.op(OP_ADD_CONST, pk->c_gamma);
+        if (j > lo) {
+          pr.op(OP_MUL);
+          pr.pop();
+        }
+      }
+      pr.op(OP_STORE, 2 * s);
+      pr.pop();
+      for (uint32_t j = lo; j < hi; j++) {  // numerator: prod (v + beta*delta^j*omega^row + gamma)
+        pr.op(OP_PUSH_COL, COL(pk->sl_omega(), r0));
+        pr.push();
+        pr.op(OP_MUL_CONST, pk->c_bdelta + j);
+        pr.op(OP_ADD_COL, COL(colkind_slot_lag(pk->perm_cols[j]), r0));
+        pr.op(OP_ADD_CONST, pk->c_gamma);
+        if (j > lo) {
+          pr.op(OP_MUL);
+          pr.pop();
+        }
+      }
+      pr.op(OP_STORE, 2 * s + 1);
+      pr.pop();
+    }
+    std::vector<Fr*> outs(2 * ns);
+    for (uint32_t s = 0; s < ns; s++) outs[2 * s] = pk->frac + (size_t)s * n, outs[2 * s + 1] = pk->zp() + (size_t)s * n;
+    KG_TRY(dalloc(ctx, pk, &pk->d_outs_pfrac, outs.size()));
+    KG_TRY(h2d(ctx, pk->d_outs_pfrac, outs.data(), outs.size() * sizeof(Fr*)));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  // (3) lookup fractions: den = (a'+beta)(s'+gamma) -> frac[l]; num = (ci+beta)(ct+gamma) -> zl[l]
+  {
+    Program& pr = pk->prog_lfrac;
+    for (uint32_t l = 0; l < L; l++) {
+      pr.op(OP_PUSH_COL, COL(pk->sl_la(l), r0));
+      pr.push();
+      pr.op(OP_ADD_CONST, pk->c_beta);
+      pr.op(OP_PUSH_COL, COL(pk->sl_ls(l), r0));
+      pr.push();
+      pr.op(OP_ADD_CONST, pk->c_gamma);
+      pr.op(OP_MUL);
+      pr.pop();
+      pr.op(OP_STORE, 2 * l);
+      pr.pop();
+      pr.op(OP_PUSH_COL, COL(pk->sl_ci(l), r0));
+      pr.push();
+      pr.op(OP_ADD_CONST, pk->c_beta);
+      pr.op(OP_PUSH_COL, COL(pk->sl_ct(l), r0));
+      pr.push();
+      pr.op(OP_ADD_CONST, pk->c_gamma);
+      pr.op(OP_MUL);
+      pr.pop();
+      pr.op(OP_STORE, 2 * l + 1);
+      pr.pop();
+    }
+    std::vector<Fr*> outs(2 * L);
+    for (uint32_t l = 0; l < L; l++) outs[2 * l] = pk->frac + (size_t)l * n, outs[2 * l + 1] = pk->zl() + (size_t)l * n;
+    KG_TRY(dalloc(ctx, pk, &pk->d_outs_lfrac, outs.size()));
+    KG_TRY(h2d(ctx, pk->d_outs_lfrac, outs.data(), outs.size() * sizeof(Fr*)));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  // (4) the h(X) numerator: gates, permutation, lookups — evaluation.rs evaluate_h order
+  {
+    Program& pr = pk->prog_h;
+    auto colkind_slot_ext = colkind_slot_lag;  // fixed/advice/instance share slot numbers in both tables
+    for (uint32_t g = 0; g < pk->num_gates; g++) {
+      KG_TRY(emit_expr(ctx, pk, pr, pk->exprs[g]));
+      pr.op(OP_ACC);
+      pr.pop();
+    }
+    if (ns > 0) {
+      // l_0 * (1 - z_0)
+      pr.op(OP_PUSH_CONST, pk->c_one); pr.push();
+      pr.op(OP_SUB_COL, COL(pk->se_zp(0), r0));
+      pr.op(OP_MUL_COL, COL(pk->se_l0(), r0));
+      pr.op(OP_ACC); pr.pop();
+      // l_last * (z_l^2 - z_l)
+      pr.op(OP_PUSH_COL, COL(pk->se_zp(ns - 1), r0)); pr.push();
+      pr.op(OP_SQR);
+      pr.op(OP_SUB_COL, COL(pk->se_zp(ns - 1), r0));
+      pr.op(OP_MUL_COL, COL(pk->se_llast(), r0));
+      pr.op(OP_ACC); pr.pop();
+      // l_0 * (z_i - z_{i-1}(omega^last X))
+      for (uint32_t s = 1; s < ns; s++) {
+        pr.op(OP_PUSH_COL, COL(pk->se_zp(s), r0)); pr.push();
+        pr.op(OP_SUB_COL, COL(pk->se_zp(s - 1), rlast));
+        pr.op(OP_MUL_COL, COL(pk->se_l0(), r0));
+        pr.op(OP_ACC); pr.pop();
+      }
+      // l_active * (z_i(omega X) prod(v + beta sigma + gamma) - z_i(X) prod(v + beta delta^j X + gamma))
+      for (uint32_t s = 0; s < ns; s++) {
+        uint32_t lo = s * pk->chunk, hi = std::min(S, lo + pk->chunk);
+        pr.op(OP_PUSH_COL, COL(pk->se_zp(s), r1)); pr.push();
+        for (uint32_t j = lo; j < hi; j++) {
+          pr.op(OP_PUSH_COL, COL(pk->se_sigma(j), r0)); pr.push();
+          pr.op(OP_MUL_CONST, pk->c_beta);
+          pr.op(OP_ADD_COL, COL(colkind_slot_ext(pk->perm_cols[j]), r0));
+          pr.op(OP_ADD_CONST, pk->c_gamma);
+          pr.op(OP_MUL); pr.pop();
+        }
+        pr.op(OP_PUSH_COL, COL(pk->se_zp(s), r0)); pr.push();
+        for (uint32_t j = lo; j < hi; j++) {
+          pr.op(OP_PUSH_COL, COL(pk->se_x(), r0)); pr.push();
+          pr.op(OP_MUL_CONST, pk->c_bdelta + j);
+          pr.op(OP_ADD_COL, COL(colkind_slot_ext(pk->perm_cols[j]), r0));
+          pr.op(OP_ADD_CONST, pk->c_gamma);
+          pr.op(OP_MUL); pr.pop();
+        }
+        pr.op(OP_SUB); pr.pop();
+        pr.op(OP_MUL_COL, COL(pk->se_lactive(), r0));
+        pr.op(OP_ACC); pr.pop();
+      }
+    }
+    uint32_t e = pk->num_gates;
+    for (uint32_t l = 0; l < L; l++) {
+      const uint32_t ni = pk->lookup_shape[l].first, nt = pk->lookup_shape[l].second;
+      // l_0 * (1 - z)
+      pr.op(OP_PUSH_CONST, pk->c_one); pr.push();
+      pr.op(OP_SUB_COL, COL(pk->se_zl(l), r0));
+      pr.op(OP_MUL_COL, COL(pk->se_l0(), r0));
+      pr.op(OP_ACC); pr.pop();
+      // l_last * (z^2 - z)
+      pr.op(OP_PUSH_COL, COL(pk->se_zl(l), r0)); pr.push();
+      pr.op(OP_SQR);
+      pr.op(OP_SUB_COL, COL(pk->se_zl(l), r0));
+      pr.op(OP_MUL_COL, COL(pk->se_llast(), r0));
+      pr.op(OP_ACC); pr.pop();
+      // l_active * (z(wX)(a'+beta)(s'+gamma) - z(X)(ci+beta)(ct+gamma))
+      pr.op(OP_PUSH_COL, COL(pk->se_zl(l), r1)); pr.push();
+      pr.op(OP_PUSH_COL, COL(pk->se_la(l), r0)); pr.push();
+      pr.op(OP_ADD_CONST, pk->c_beta);
+      pr.op(OP_MUL); pr.pop();
+      pr.op(OP_PUSH_COL, COL(pk->se_ls(l), r0)); pr.push();
+      pr.op(OP_ADD_CONST, pk->c_gamma);
+      pr.op(OP_MUL); pr.pop();
+      pr.op(OP_PUSH_COL, COL(pk->se_zl(l), r0)); pr.push();
+      KG_TRY(emit_compressed(ctx, pk, pr, e, ni));
+      pr.op(OP_ADD_CONST, pk->c_beta);
+      pr.op(OP_MUL); pr.pop();
+      KG_TRY(emit_compressed(ctx, pk, pr, e + ni, nt));
+      pr.op(OP_ADD_CONST, pk->c_gamma);
+      pr.op(OP_MUL); pr.pop();
+      pr.op(OP_SUB); pr.pop();
+      pr.op(OP_MUL_COL, COL(pk->se_lactive(), r0));
+      pr.op(OP_ACC); pr.pop();
+      // l_0 * (a' - s')
+      pr.op(OP_PUSH_COL, COL(pk->se_la(l), r0)); pr.push();
+      pr.op(OP_SUB_COL, COL(pk->se_ls(l), r0));
+      pr.op(OP_MUL_COL, COL(pk->se_l0(), r0));
+      pr.op(OP_ACC); pr.pop();
+      // l_active * (a' - s')(a' - a'(w^-1 X))
+      pr.op(OP_PUSH_COL, COL(pk->se_la(l), r0)); pr.push();
+      pr.op(OP_SUB_COL, COL(pk->se_ls(l), r0));
+      pr.op(OP_PUSH_COL, COL(pk->se_la(l), r0)); pr.push();
+      pr.op(OP_SUB_COL, COL(pk->se_la(l), rm1));
+      pr.op(OP_MUL); pr.pop();
+      pr.op(OP_MUL_COL, COL(pk->se_lactive(), r0));
+      pr.op(OP_ACC); pr.pop();
+      e += ni + nt;
+    }
+  }
+  if (pk->rots.rots.size() > 255) {
+    amdzk_pk_free(ctx, pk);
+    ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "keygen: more than 255 distinct rotations");
+  }
+  KG_TRY(upload_program(ctx, pk, pk->prog_compress));
+  KG_TRY(upload_program(ctx, pk, pk->prog_pfrac));
+  KG_TRY(upload_program(ctx, pk, pk->prog_lfrac));
+  KG_TRY(upload_program(ctx, pk, pk->prog_h));
+  {
+    std::vector<int32_t> rl(pk->rots.rots), re(pk->rots.rots);
+    const int32_t scale = 1 << (pk->ek - pk->k);
+    for (auto& v : re) v *= scale;
+    KG_TRY(dalloc(ctx, pk, &pk->d_rot_lag, rl.size()));
+    KG_TRY(dalloc(ctx, pk, &pk->d_rot_ext, re.size()));
+    KG_TRY(h2d(ctx, pk->d_rot_lag, rl.data(), rl.size() * 4));
+    KG_TRY(h2d(ctx, pk->d_rot_ext, re.data(), re.size() * 4));
+    KG_TRY(dalloc(ctx, pk, &pk->d_consts, pk->consts.size()));
+    KG_TRY(h2d(ctx, pk->d_consts, pk->consts.data(), pk->consts.size() * 32));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  // l_active coset = 1 - (l_last + l_blind): lactive_c holds l_blind's coset; tiny one-off program
+  {
+    Program pr;
+    pr.op(OP_PUSH_CONST, pk->c_one); pr.push();
+    pr.op(OP_SUB_COL, COL(pk->se_llast(), r0));
+    pr.op(OP_SUB_COL, COL(pk->se_lactive(), r0));
+    pr.op(OP_STORE, 0); pr.pop();
+    KG_TRY(upload_program(ctx, pk, pr));
+    Fr** d_out = nullptr;
+    KG_TRY(dalloc(ctx, pk, &d_out, 1));
+    Fr* tgt = pk->lactive_c;
+    KG_TRY(h2d(ctx, d_out, &tgt, sizeof(Fr*)));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    KG_TRY(run_program(ctx, pk, pr, true, d_out, nullptr, "expr_l_active"));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+#undef KG_TRY
+  *out = pk;
+  return AMDZK_OK;
+}
+
+// VK material a verifier needs: commitments of the fixed columns and of the permutation polynomials.
+int amdzk_pk_commitments(const amdzk_pk* pk, uint64_t* fixed_out /* F x 8 */, uint64_t* perm_out /* S x 8 */) {
+  if (!pk) return AMDZK_E_INVALID;
+  if (fixed_out && pk->F) memcpy(fixed_out, pk->fixed_commitments.data(), (size_t)pk->F * 64);
+  if (perm_out && pk->S) memcpy(perm_out, pk->perm_commitments.data(), (size_t)pk->S * 64);
+  return AMDZK_OK;
+}
+
+int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances, const size_t* instance_lens, const void* d_advice,
+                       size_t advice_stride, uint64_t rng_seed, uint8_t* proof_out, size_t proof_cap, size_t* proof_len) {
+  if (!ctx) return AMDZK_E_INVALID;
+  if (!pk || !proof_len || (pk->A && !d_advice)) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: null argument");
+  const size_t n = pk->n, ext = pk->ext;
+  const uint32_t F = pk->F, A = pk->A, I = pk->I, S = pk->S, L = pk->L, ns = pk->nsets, bf = pk->bf;
+  const size_t usable = n - (bf + 1);
+  if (advice_stride < n) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: advice stride < n");
+  ChaCha20Rng rng(rng_seed);
+  Blake2bWrite T;
+  auto upload_small = [&](const std::vector<Fr>& v, size_t off_elems) -> int {
+    if (off_elems + v.size() > pk->small_cap) ZK_FAIL(ctx, AMDZK_E_NOMEM, "create_proof: small buffer overflow");
+    return h2d(ctx, pk->small + off_elems, v.data(), v.size() * 32);
+  };
+  auto write_points = [&](const std::vector<G1Affine>& pts, const char* label) -> int {
+    for (auto& p : pts) {
+      trace_pt(label, p);
+      if (!T.write_point(p)) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: %s commitment is the identity (cannot write points at infinity to the transcript)", label);
+    }
+    return AMDZK_OK;
+  };
+  // blinding tails: draw cnt scalars per column (column-major draw order), scatter into rows [row0, row0+cnt)
+  auto blind_rows = [&](Fr* d_cols, uint32_t ncols, size_t row0, uint32_t cnt, const std::vector<Fr>& vals) -> int {
+    ZK_TRY(upload_small(vals, 0));
+    ZK_TRY(zk_scatter_rows(ctx, d_cols, n, row0, pk->small, cnt, ncols));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `vals` is a host temporary
+    return AMDZK_OK;
+  };
+
+  // 0. vk, instances
+  T.common_scalar(pk->transcript_repr);
+  {
+    std::vector<Fr> iv((size_t)I * n, Fr::zero());
+    for (uint32_t c = 0; c < I; c++) {
+      size_t len = instance_lens ? instance_lens[c] : 0;
+      if (len > usable) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: instance column %u too long (InstanceTooLarge)", c);
+      for (size_t i = 0; i < len; i++) {
+        memcpy(iv[(size_t)c * n + i].l, instances[c] + 4 * i, 32);
+        T.common_scalar(iv[(size_t)c * n + i]);
+      }
+    }
+    ZK_TRY(h2d(ctx, pk->inst(), iv.data(), iv.size() * 32));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  // 1. advice: copy in, blind the unusable rows of every column, draw the (unused) blinds, commit
+  if (A) {
+    ZK_HIP(ctx, hipMemcpy2DAsync(pk->adv(), n * 32, d_advice, advice_stride * 32, n * 32, A, hipMemcpyDeviceToDevice, ctx->stream));
+    std::vector<Fr> tail((size_t)A * (bf + 1));
+    for (auto& v : tail) v = rng.fr();
+    for (uint32_t c = 0; c < A; c++) (void)rng.fr();
+    ZK_TRY(blind_rows(pk->adv(), A, usable, bf + 1, tail));
+    std::vector<G1Affine> cm;
+    ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G_LAGRANGE, pk->adv(), A, cm));
+    ZK_TRY(write_points(cm, "advice"));
+  }
+  Fr theta = T.squeeze_challenge();
+  trace_fr("theta", theta);
+  pk->consts[pk->c_theta] = theta;
+  ZK_TRY(h2d(ctx, pk->d_consts + pk->c_theta, &pk->consts[pk->c_theta], 32));
+  // 2. lookups: compress, permute (host, round 1), blind, commit
+  if (L) {
+    ZK_TRY(run_program(ctx, pk, pk->prog_compress, false, pk->d_outs_compress, nullptr, "expr_lookup_compress"));
+    // canonical copies for sorting: scratch <- ci | ct, to_repr on device
+    std::vector<std::array<uint64_t, 4>> hin((size_t)L * n), htab((size_t)L * n), ha((size_t)L * n), hs((size_t)L * n);
+    ZK_TRY(d2d(ctx, pk->la(), pk->ci, (size_t)L * n * 32));
+    ZK_TRY(d2d(ctx, pk->ls(), pk->ct, (size_t)L * n * 32));
+    ZK_TRY(amdzk_fr_to_repr_dev(ctx, pk->la(), (size_t)2 * L * n));
+    ZK_TRY(d2h(ctx, hin.data(), pk->la(), (size_t)L * n * 32));
+    ZK_TRY(d2h(ctx, htab.data(), pk->ls(), (size_t)L * n * 32));
+    std::vector<int> ok(L, 1);
+    {
+      unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+      nt = std::min<unsigned>(nt, L);
+      std::vector<std::thread> th;
+      for (unsigned t = 0; t < nt; t++)
+        th.emplace_back([&, t]() {
+          for (uint32_t l = t; l < L; l += nt)
+            ok[l] = permute_pair(&hin[(size_t)l * n], &htab[(size_t)l * n], usable, &ha[(size_t)l * n], &hs[(size_t)l * n]) ? 1 : 0;
+        });
+      for (auto& x : th) x.join();
+    }
+    for (uint32_t l = 0; l < L; l++)
+      if (!ok[l]) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: lookup %u input not in table (ConstraintSystemFailure)", l);
+    ZK_TRY(h2d(ctx, pk->la(), ha.data(), (size_t)L * n * 32));
+    ZK_TRY(h2d(ctx, pk->ls(), hs.data(), (size_t)L * n * 32));
+    ZK_TRY(amdzk_fr_from_raw_dev(ctx, pk->la(), (size_t)2 * L * n));
+    // RNG order per lookup: a' tail, s' tail, blind(a'), blind(s')
+    std::vector<Fr> ta((size_t)L * (bf + 1)), ts((size_t)L * (bf + 1));
+    for (uint32_t l = 0; l < L; l++) {
+      for (uint32_t i = 0; i <= bf; i++) ta[(size_t)l * (bf + 1) + i] = rng.fr();
+      for (uint32_t i = 0; i <= bf; i++) ts[(size_t)l * (bf + 1) + i] = rng.fr();
+      (void)rng.fr();
+      (void)rng.fr();
+    }
+    ZK_TRY(blind_rows(pk->la(), L, usable, bf + 1, ta));
+    ZK_TRY(blind_rows(pk->ls(), L, usable, bf + 1, ts));
+    std::vector<G1Affine> cm;
+    ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G_LAGRANGE, pk->la(), 2 * L, cm));
+    for (uint32_t l = 0; l < L; l++) {
+      std::vector<G1Affine> two = {cm[l], cm[L + l]};
+      ZK_TRY(write_points(two, "lookup_permuted"));
+    }
+  }
+  Fr beta = T.squeeze_challenge();
+  Fr gamma = T.squeeze_challenge();
+  trace_fr("beta", beta);
+  trace_fr("gamma", gamma);
+  pk->consts[pk->c_beta] = beta;
+  pk->consts[pk->c_gamma] = gamma;
+  {
+    Fr cur = beta, delta = fr_delta();
+    for (uint32_t j = 0; j < S; j++) {
+      pk->consts[pk->c_bdelta + j] = cur;
+      cur = mul(cur, delta);
+    }
+    ZK_TRY(h2d(ctx, pk->d_consts + pk->c_beta, &pk->consts[pk->c_beta], (size_t)(pk->consts.size() - pk->c_beta) * 32));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  // 3. permutation grand products
+  if (ns) {
+    ZK_TRY(run_program(ctx, pk, pk->prog_pfrac, false, pk->d_outs_pfrac, nullptr, "expr_perm_fractions"));
+    ZK_TRY(zk_batch_invert(ctx, pk->frac, pk->scratch, (size_t)ns * n));
+    ZK_TRY(zk_mul_elem(ctx, pk->zp(), pk->frac, (size_t)ns * n));
+    ZK_TRY(zk_running_product(ctx, pk->zp(), ns, n, n, true, usable, pk->scan_tmp));
+    std::vector<Fr> tail((size_t)ns * bf);
+    for (uint32_t s = 0; s < ns; s++) {
+      for (uint32_t i = 0; i < bf; i++) tail[(size_t)s * bf + i] = rng.fr();
+      (void)rng.fr();
+    }
+    ZK_TRY(blind_rows(pk->zp(), ns, n - bf, bf, tail));
+    std::vector<G1Affine> cm;
+    ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G_LAGRANGE, pk->zp(), ns, cm));
+    ZK_TRY(write_points(cm, "perm_z"));
+  }
+  // 4. lookup grand products
+  if (L) {
+    ZK_TRY(run_program(ctx, pk, pk->prog_lfrac, false, pk->d_outs_lfrac, nullptr, "expr_lookup_fractions"));
+    ZK_TRY(zk_batch_invert(ctx, pk->frac, pk->scratch, (size_t)L * n));
+    ZK_TRY(zk_mul_elem(ctx, pk->zl(), pk->frac, (size_t)L * n));
+    ZK_TRY(zk_running_product(ctx, pk->zl(), L, n, n, false, 0, pk->scan_tmp));
+    std::vector<Fr> tail((size_t)L * bf);
+    for (uint32_t l = 0; l < L; l++) {
+      for (uint32_t i = 0; i < bf; i++) tail[(size_t)l * bf + i] = rng.fr();
+      (void)rng.fr();
+    }
+    ZK_TRY(blind_rows(pk->zl(), L, n - bf, bf, tail));
+    std::vector<G1Affine> cm;
+    ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G_LAGRANGE, pk->zl(), L, cm));
+    ZK_TRY(write_points(cm, "lookup_z"));
+  }
+  // 5. vanishing: random polynomial (coefficient form), commit with g
+  {
+    std::vector<Fr> rp(n);
+    for (auto& v : rp) v = rng.fr();
+    (void)rng.fr();
+    ZK_TRY(h2d(ctx, pk->rnd, rp.data(), n * 32));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<G1Affine> cm;
+    ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G, pk->rnd, 1, cm));
+    ZK_TRY(write_points(cm, "random_poly"));
+  }
+  Fr y = T.squeeze_challenge();
+  trace_fr("y", y);
+  pk->consts[pk->c_y] = y;
+  ZK_TRY(h2d(ctx, pk->d_consts + pk->c_y, &pk->consts[pk->c_y], 32));
+  // 6. every committed column: Lagrange -> coefficients -> extended coset; then h(X)
+  ZK_TRY(amdzk_lagrange_to_coeff_dev(ctx, pk->dom, pk->P, pk->NP, n));
+  ZK_TRY(amdzk_coeff_to_extended_dev(ctx, pk->dom, pk->P, n, pk->PC, ext, pk->NP));
+  ZK_TRY(run_program(ctx, pk, pk->prog_h, true, nullptr, pk->hq, "expr_evaluate_h"));
+  ZK_TRY(amdzk_divide_by_vanishing_dev(ctx, pk->dom, pk->hq, 1, ext));
+  ZK_TRY(amdzk_extended_to_coeff_dev(ctx, pk->dom, pk->hq, 1, ext));
+  {
+    for (uint32_t i = 0; i < pk->qdeg; i++) (void)rng.fr();  // h_blinds
+    std::vector<G1Affine> cm;
+    ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G, pk->hq, pk->qdeg, cm));  // pieces are consecutive n-blocks of hq
+    ZK_TRY(write_points(cm, "h_piece"));
+  }
+  Fr x = T.squeeze_challenge();
+  trace_fr("x", x);
+  Fr xn = pow_u64(x, n);
+  // h_poly = sum_i piece_i * xn^i
+  {
+    std::vector<const Fr*> pp(pk->qdeg);
+    std::vector<Fr> cf(pk->qdeg);
+    Fr cur = Fr::one();
+    for (uint32_t i = 0; i < pk->qdeg; i++) {
+      pp[i] = pk->hq + (size_t)i * n;
+      cf[i] = cur;
+      cur = mul(cur, xn);
+    }
+    ZK_TRY(h2d(ctx, pk->ptrs, pp.data(), pp.size() * sizeof(Fr*)));
+    ZK_TRY(upload_small(cf, 0));
+    ZK_TRY(zk_lincomb(ctx, (const Fr* const*)pk->ptrs, pk->small, pk->qdeg, pk->hpoly, n, false));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  // 7. evaluations. One list of (polynomial, rotation) in proof order, then the two extra
+  //    evaluations SHPLONK needs (h_poly at x; random at x is already in the list).
+  struct Q {
+    const Fr* poly;
+    int rot;
+    Fr point, eval;
+  };
+  std::vector<Q> ev;
+  auto addq = [&](const Fr* p, int rot) { ev.push_back(Q{p, rot, rotate_omega(pk, x, rot), Fr::zero()}); };
+  Fr* adv_poly = pk->adv();
+  for (auto& q : pk->advice_queries) addq(adv_poly + (size_t)q.first * n, q.second);
+  for (auto& q : pk->fixed_queries) addq(pk->fixed_poly + (size_t)q.first * n, q.second);
+  addq(pk->rnd, 0);
+  for (uint32_t i = 0; i < S; i++) addq(pk->sigma_poly + (size_t)i * n, 0);
+  for (uint32_t s = 0; s < ns; s++) {
+    addq(pk->zp() + (size_t)s * n, 0);
+    addq(pk->zp() + (size_t)s * n, 1);
+    if (s + 1 < ns) addq(pk->zp() + (size_t)s * n, -(int)(bf + 1));
+  }
+  for (uint32_t l = 0; l < L; l++) {
+    addq(pk->zl() + (size_t)l * n, 0);
+    addq(pk->zl() + (size_t)l * n, 1);
+    addq(pk->la() + (size_t)l * n, 0);
+    addq(pk->la() + (size_t)l * n, -1);
+    addq(pk->ls() + (size_t)l * n, 0);
+  }
+  const size_t n_written = ev.size();
+  addq(pk->hpoly, 0);
+  {
+    const size_t nq = ev.size();
+    if (nq > pk->ptrs_cap || 2 * nq > pk->small_cap) ZK_FAIL(ctx, AMDZK_E_NOMEM, "create_proof: too many queries (%zu)", nq);
+    std::vector<const Fr*> pp(nq);
+    std::vector<Fr> pts(nq);
+    for (size_t i = 0; i < nq; i++) pp[i] = ev[i].poly, pts[i] = ev[i].point;
+    ZK_TRY(h2d(ctx, pk->ptrs, pp.data(), nq * sizeof(Fr*)));
+    ZK_TRY(upload_small(pts, 0));
+    ZK_TRY(zk_poly_eval(ctx, (const Fr* const*)pk->ptrs, pk->small, pk->small + nq, nq, (uint32_t)n));
+    std::vector<Fr> res(nq);
+    ZK_TRY(d2h(ctx, res.data(), pk->small + nq, nq * 32));
+    for (size_t i = 0; i < nq; i++) ev[i].eval = res[i];
+    for (size_t i = 0; i < n_written; i++) T.write_scalar(ev[i].eval);
+  }
+  auto eval_of = [&](const Fr* p, int rot) -> Fr {
+    for (auto& q : ev)
+      if (q.poly == p && q.rot == rot) return q.eval;
+    return Fr::zero();
+  };
+  // 8. multiopen queries in upstream order
+  struct PQ {
+    const Fr* poly;
+    Fr point, eval;
+  };
+  std::vector<PQ> queries;
+  auto addpq = [&](const Fr* p, int rot) { queries.push_back(PQ{p, rotate_omega(pk, x, rot), eval_of(p, rot)}); };
+  for (auto& q : pk->advice_queries) addpq(adv_poly + (size_t)q.first * n, q.second);
+  for (uint32_t s = 0; s < ns; s++) {
+    addpq(pk->zp() + (size_t)s * n, 0);
+    addpq(pk->zp() + (size_t)s * n, 1);
+  }
+  for (int s = (int)ns - 2; s >= 0; s--) addpq(pk->zp() + (size_t)s * n, -(int)(bf + 1));
+  for (uint32_t l = 0; l < L; l++) {
+    addpq(pk->zl() + (size_t)l * n, 0);
+    addpq(pk->la() + (size_t)l * n, 0);
+    addpq(pk->ls() + (size_t)l * n, 0);
+    addpq(pk->la() + (size_t)l * n, -1);
+    addpq(pk->zl() + (size_t)l * n, 1);
+  }
+  for (auto& q : pk->fixed_queries) addpq(pk->fixed_poly + (size_t)q.first * n, q.second);
+  for (uint32_t i = 0; i < S; i++) addpq(pk->sigma_poly + (size_t)i * n, 0);
+  addpq(pk->hpoly, 0);
+  addpq(pk->rnd, 0);
+
+  // 9. SHPLONK (multiopen/shplonk/prover.rs [UP])
+  {
+    // construct_intermediate_sets
+    struct CR {
+      const Fr* poly;
+      std::vector<std::array<uint64_t, 4>> pts;  // sorted, distinct (canonical)
+    };
+    std::vector<CR> com_rot;
+    std::vector<std::array<uint64_t, 4>> super;
+    auto insert_sorted = [](std::vector<std::array<uint64_t, 4>>& v, const std::array<uint64_t, 4>& p) {
+      auto it = std::lower_bound(v.begin(), v.end(), p, fr_less_canon);
+      if (it == v.end() || *it != p) v.insert(it, p);
+    };
+    std::vector<std::array<uint64_t, 4>> qcanon(queries.size());
+    for (size_t i = 0; i < queries.size(); i++) {
+      qcanon[i] = canon(queries[i].point);
+      insert_sorted(super, qcanon[i]);
+      bool found = false;
+      for (auto& cr : com_rot)
+        if (cr.poly == queries[i].poly) {
+          insert_sorted(cr.pts, qcanon[i]);
+          found = true;
+          break;
+        }
+      if (!found) com_rot.push_back(CR{queries[i].poly, {qcanon[i]}});
+    }
+    struct RS {
+      std::vector<std::array<uint64_t, 4>> pts;
+      std::vector<const Fr*> polys;
+    };
+    std::vector<RS> rsets;
+    for (auto& cr : com_rot) {
+      bool found = false;
+      for (auto& rs : rsets)
+        if (rs.pts == cr.pts) {
+          rs.polys.push_back(cr.poly);
+          found = true;
+          break;
+        }
+      if (!found) rsets.push_back(RS{cr.pts, {cr.poly}});
+    }
+    if (rsets.size() > 16) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "create_proof: more than 16 rotation sets");
+    auto point_fr = [&](const std::array<uint64_t, 4>& c) {
+      Fr r;
+      memcpy(r.l, c.data(), 32);
+      return to_mont(r);
+    };
+    auto get_eval = [&](const Fr* poly, const std::array<uint64_t, 4>& pt) -> Fr {
+      for (size_t i = 0; i < queries.size(); i++)
+        if (queries[i].poly == poly && qcanon[i] == pt) return queries[i].eval;
+      return Fr::zero();
+    };
+    Fr ys = T.squeeze_challenge();
+    Fr v = T.squeeze_challenge();
+    trace_fr("shplonk_y", ys);
+    trace_fr("shplonk_v", v);
+    const size_t nr = rsets.size();
+    std::vector<std::vector<Fr>> set_pts(nr);
+    std::vector<std::vector<std::vector<Fr>>> lows(nr);  // [set][commitment] low-degree equivalent
+    for (size_t i = 0; i < nr; i++) {
+      for (auto& c : rsets[i].pts) set_pts[i].push_back(point_fr(c));
+      for (auto* poly : rsets[i].polys) {
+        std::vector<Fr> evals;
+        for (auto& c : rsets[i].pts) evals.push_back(get_eval(poly, c));
+        lows[i].push_back(lagrange_interpolate(set_pts[i], evals));
+      }
+    }
+    // L_i = sum_j y^j P_ij ; N_i = (L_i - sum_j y^j R_ij) / prod (X - p)
+    size_t maxm = 0;
+    for (size_t i = 0; i < nr; i++) {
+      const size_t m = rsets[i].polys.size();
+      if (m > pk->ptrs_cap || m > pk->small_cap / 2) ZK_FAIL(ctx, AMDZK_E_NOMEM, "create_proof: rotation set too large");
+      std::vector<Fr> cf(m);
+      Fr cur = Fr::one();
+      std::vector<Fr> lowsum(set_pts[i].size(), Fr::zero());
+      for (size_t j = 0; j < m; j++) {
+        cf[j] = cur;
+        for (size_t t = 0; t < lows[i][j].size(); t++) lowsum[t] = add(lowsum[t], mul(cur, lows[i][j][t]));
+        cur = mul(cur, ys);
+      }
+      maxm = std::max(maxm, set_pts[i].size());
+      ZK_TRY(h2d(ctx, pk->ptrs, rsets[i].polys.data(), m * sizeof(Fr*)));
+      ZK_TRY(upload_small(cf, 0));
+      ZK_TRY(upload_small(lowsum, m));
+      Fr* Li = pk->sets_L + i * n;
+      Fr* Ni = pk->sets_N + i * n;
+      ZK_TRY(zk_lincomb(ctx, (const Fr* const*)pk->ptrs, pk->small, (uint32_t)m, Li, n, false));
+      ZK_TRY(d2d(ctx, Ni, Li, n * 32));
+      ZK_TRY(zk_sub_low(ctx, Ni, pk->small + m, (uint32_t)lowsum.size()));
+      ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    for (size_t step = 0; step < maxm; step++) {  // one root per set per launch
+      std::vector<Fr*> pp;
+      std::vector<Fr> roots;
+      for (size_t i = 0; i < nr; i++)
+        if (step < set_pts[i].size()) {
+          pp.push_back(pk->sets_N + i * n);
+          roots.push_back(set_pts[i][step]);
+        }
+      ZK_TRY(h2d(ctx, pk->ptrs, pp.data(), pp.size() * sizeof(Fr*)));
+      ZK_TRY(upload_small(roots, 0));
+      ZK_TRY(zk_kate_div(ctx, (Fr* const*)pk->ptrs, pk->small, pp.size(), (uint32_t)n));
+      ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    {
+      std::vector<const Fr*> pp(nr);
+      std::vector<Fr> cf(nr);
+      Fr cur = Fr::one();
+      for (size_t i = 0; i < nr; i++) {
+        pp[i] = pk->sets_N + i * n;
+        cf[i] = cur;
+        cur = mul(cur, v);
+      }
+      ZK_TRY(h2d(ctx, pk->ptrs, pp.data(), nr * sizeof(Fr*)));
+      ZK_TRY(upload_small(cf, 0));
+      ZK_TRY(zk_lincomb(ctx, (const Fr* const*)pk->ptrs, pk->small, (uint32_t)nr, pk->hx, n, false));
+      ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    std::vector<G1Affine> cm;
+    ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G, pk->hx, 1, cm));
+    ZK_TRY(write_points(cm, "shplonk_h1"));
+    Fr u = T.squeeze_challenge();
+    trace_fr("u", u);
+    // l(X) = sum_i v^i z_i (L_i - r_i) - zt(u) h(X);  then / (X - u) / z_0
+    Fr zt = Fr::one();
+    for (auto& c : super) zt = mul(zt, sub(u, point_fr(c)));
+    std::vector<const Fr*> pp(nr + 1);
+    std::vector<Fr> cf(nr + 1);
+    Fr cur = Fr::one(), z0 = Fr::one(), cterm = Fr::zero();
+    for (size_t i = 0; i < nr; i++) {
+      Fr zi = Fr::one();
+      for (auto& c : super)
+        if (!std::binary_search(rsets[i].pts.begin(), rsets[i].pts.end(), c, fr_less_canon)) zi = mul(zi, sub(u, point_fr(c)));
+      if (i == 0) z0 = zi;
+      Fr ri = Fr::zero(), yp = Fr::one();
+      for (size_t j = 0; j < lows[i].size(); j++) {
+        ri = add(ri, mul(yp, eval_small(lows[i][j], u)));
+        yp = mul(yp, ys);
+      }
+      Fr w = mul(cur, zi);
+      pp[i] = pk->sets_L + i * n;
+      cf[i] = w;
+      cterm = add(cterm, mul(w, ri));
+      cur = mul(cur, v);
+    }
+    pp[nr] = pk->hx;
+    cf[nr] = neg(zt);
+    Fr* lx = pk->sets_N;  // reuse
+    ZK_TRY(h2d(ctx, pk->ptrs, pp.data(), (nr + 1) * sizeof(Fr*)));
+    ZK_TRY(upload_small(cf, 0));
+    std::vector<Fr> ct1 = {cterm};
+    ZK_TRY(upload_small(ct1, nr + 1));
+    ZK_TRY(zk_lincomb(ctx, (const Fr* const*)pk->ptrs, pk->small, (uint32_t)(nr + 1), lx, n, false));
+    ZK_TRY(zk_sub_low(ctx, lx, pk->small + nr + 1, 1));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<Fr*> one_p = {lx};
+    std::vector<Fr> one_r = {u};
+    ZK_TRY(h2d(ctx, pk->ptrs, one_p.data(), sizeof(Fr*)));
+    ZK_TRY(upload_small(one_r, 0));
+    ZK_TRY(zk_kate_div(ctx, (Fr* const*)pk->ptrs, pk->small, 1, (uint32_t)n));
+    ZK_TRY(zk_scale(ctx, lx, n, inv(z0)));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G, lx, 1, cm));
+    ZK_TRY(write_points(cm, "shplonk_h2"));
+  }
+  *proof_len = T.proof.size();
+  if (proof_out) {
+    if (proof_cap < T.proof.size()) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: proof buffer too small (%zu < %zu)", proof_cap, T.proof.size());
+    memcpy(proof_out, T.proof.data(), T.proof.size());
+  }
+  (void)F;
+  return AMDZK_OK;
+}
+
+}  // extern "C"

@@ -59,6 +59,10 @@ def lib():
         "amdzk_coeff_to_extended_dev": (i32, [vp, vp, vp, sz, vp, sz, sz]),
         "amdzk_extended_to_coeff_dev": (i32, [vp, vp, vp, sz, sz]),
         "amdzk_divide_by_vanishing_dev": (i32, [vp, vp, vp, sz, sz]),
+        "amdzk_keygen": (i32, [vp, vp, vp, vp, vp, vp, C.POINTER(vp)]),
+        "amdzk_pk_free": (None, [vp, vp]),
+        "amdzk_pk_commitments": (i32, [vp, vp, vp]),
+        "amdzk_create_proof": (i32, [vp, vp, C.POINTER(vp), C.POINTER(sz), vp, sz, C.c_uint64, vp, sz, C.POINTER(sz)]),
         "amdzk_timer_start": (i32, [vp]),
         "amdzk_timer_stop": (i32, [vp, C.POINTER(C.c_float)]),
         "amdzk_prof_enable": (i32, [vp, i32]),

@@ -1,0 +1,369 @@
+"""Mirror of halo2_proofs::plonk::{ConstraintSystem, Expression, Column, keygen, create_proof}
+(v2023_01_20 [UP], /root/reference/Cargo.lock:469-471) — the interface the reference's circuits
+implement and call: `Circuit::configure(meta)` (/root/reference/src/lib.rs:295-326,
+src/signal.rs:27-49, src/conditional_secrets.rs:81-187, src/timestamp.rs:58-138).
+
+This module is host-side description only: it records columns, queries, gates, lookups and the
+permutation exactly the way upstream's ConstraintSystem does (query indices in first-use order,
+`degree()`, `blinding_factors()`), and flattens the result into the arrays the C ABI takes
+(`amdzk_circuit_*`, include/amdzk.h). All O(n) proving work happens on the device.
+
+Selectors are modelled after upstream's selector compression has run, i.e. as fixed columns.
+Field constants are Python ints (canonical); they are converted to Montgomery limbs at export.
+"""
+from dataclasses import dataclass, field
+from typing import List, Tuple
+
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+ADVICE, FIXED, INSTANCE = 0, 1, 2  # upstream's `Any` ordering: Advice < Fixed < Instance
+
+
+@dataclass(frozen=True)
+class Column:
+    kind: int
+    index: int
+
+
+class Expression:
+    """plonk::Expression: Constant | Fixed | Advice | Instance | Negated | Sum | Product | Scaled."""
+
+    __slots__ = ("op", "a", "b")
+
+    def __init__(self, op, a=None, b=None):
+        self.op, self.a, self.b = op, a, b
+
+    @staticmethod
+    def constant(v):
+        return Expression("const", v % R)
+
+    def __neg__(self):
+        return Expression("neg", self)
+
+    def __add__(self, o):
+        return Expression("sum", self, _lift(o))
+
+    def __radd__(self, o):
+        return Expression("sum", _lift(o), self)
+
+    def __sub__(self, o):
+        return Expression("sum", self, Expression("neg", _lift(o)))
+
+    def __rsub__(self, o):
+        return Expression("sum", _lift(o), Expression("neg", self))
+
+    def __mul__(self, o):
+        if isinstance(o, int):
+            return Expression("scaled", self, o % R)
+        return Expression("product", self, o)
+
+    def __rmul__(self, o):
+        return self.__mul__(o)
+
+    def degree(self):
+        op = self.op
+        if op == "const":
+            return 0
+        if op in ("fixed", "advice", "instance"):
+            return 1
+        if op == "neg":
+            return self.a.degree()
+        if op == "sum":
+            return max(self.a.degree(), self.b.degree())
+        if op == "product":
+            return self.a.degree() + self.b.degree()
+        if op == "scaled":
+            return self.a.degree()
+        raise ValueError(op)
+
+    def to_tuple(self):
+        op = self.op
+        if op == "const":
+            return ("const", self.a)
+        if op in ("fixed", "advice", "instance"):
+            return (op, self.a, self.b)  # (column index, rotation)
+        if op == "neg":
+            return ("neg", self.a.to_tuple())
+        if op in ("sum", "product"):
+            return (op, self.a.to_tuple(), self.b.to_tuple())
+        if op == "scaled":
+            return ("scaled", self.a.to_tuple(), self.b)
+        raise ValueError(op)
+
+
+def _lift(o):
+    return o if isinstance(o, Expression) else Expression.constant(o)
+
+
+class VirtualCells:
+    """What `meta.create_gate(|meta| ...)` / `meta.lookup(|meta| ...)` closures receive."""
+
+    def __init__(self, cs):
+        self.cs = cs
+
+    def query_advice(self, col, rot=0):
+        assert col.kind == ADVICE
+        if self.cs._query(self.cs.advice_queries, col, rot):
+            self.cs.num_advice_queries[col.index] += 1
+        return Expression("advice", col.index, rot)
+
+    def query_fixed(self, col, rot=0):
+        assert col.kind == FIXED
+        self.cs._query(self.cs.fixed_queries, col, rot)
+        return Expression("fixed", col.index, rot)
+
+    def query_selector(self, col):
+        return self.query_fixed(col, 0)
+
+    def query_instance(self, col, rot=0):
+        assert col.kind == INSTANCE
+        self.cs._query(self.cs.instance_queries, col, rot)
+        return Expression("instance", col.index, rot)
+
+
+class ConstraintSystem:
+    def __init__(self):
+        self.num_fixed = self.num_advice = self.num_instance = 0
+        self.advice_queries: List[Tuple[Column, int]] = []
+        self.fixed_queries: List[Tuple[Column, int]] = []
+        self.instance_queries: List[Tuple[Column, int]] = []
+        self.num_advice_queries: List[int] = []
+        self.gates: List[Expression] = []       # one entry per polynomial constraint, in order
+        self.lookups: List[Tuple[List[Expression], List[Expression]]] = []
+        self.permutation_columns: List[Column] = []
+        self.minimum_degree = None
+
+    # ---- columns
+    def advice_column(self):
+        self.num_advice += 1
+        self.num_advice_queries.append(0)
+        return Column(ADVICE, self.num_advice - 1)
+
+    def fixed_column(self):
+        self.num_fixed += 1
+        return Column(FIXED, self.num_fixed - 1)
+
+    selector = fixed_column  # post-compression model
+
+    def instance_column(self):
+        self.num_instance += 1
+        return Column(INSTANCE, self.num_instance - 1)
+
+    def _query(self, lst, col, rot):
+        """query_*_index: register (column, rotation) on first use; True if it was new."""
+        if (col, rot) in lst:
+            return False
+        lst.append((col, rot))
+        return True
+
+    def enable_equality(self, col):
+        """ConstraintSystem::enable_equality: query at Rotation::cur() + add to the permutation."""
+        if col.kind == ADVICE:
+            VirtualCells(self).query_advice(col, 0)
+        elif col.kind == FIXED:
+            VirtualCells(self).query_fixed(col, 0)
+        else:
+            VirtualCells(self).query_instance(col, 0)
+        if col not in self.permutation_columns:
+            self.permutation_columns.append(col)
+
+    def create_gate(self, fn):
+        polys = fn(VirtualCells(self))
+        if isinstance(polys, Expression):
+            polys = [polys]
+        assert polys, "create_gate: gates must contain at least one constraint"
+        self.gates.extend(polys)
+
+    def lookup(self, fn):
+        """fn(meta) -> [(input_expr, table_expr), ...]"""
+        pairs = fn(VirtualCells(self))
+        self.lookups.append(([p[0] for p in pairs], [p[1] for p in pairs]))
+        return len(self.lookups) - 1
+
+    # ---- derived quantities (upstream formulas)
+    def degree(self):
+        d = 3  # permutation::Argument::required_degree() is the constant 3 upstream
+        for inputs, tables in self.lookups:
+            di = max([1] + [e.degree() for e in inputs])
+            dt = max([1] + [e.degree() for e in tables])
+            d = max(d, max(4, 2 + di + dt))
+        for g in self.gates:
+            d = max(d, g.degree())
+        return max(d, self.minimum_degree or 1)
+
+    def blinding_factors(self):
+        factors = max(self.num_advice_queries) if self.num_advice_queries else 1
+        return max(3, factors) + 2
+
+    def minimum_rows(self):
+        return self.blinding_factors() + 3
+
+    def describe(self, k):
+        """Plain-data description of the constraint system (what a Rust fork would export)."""
+        cols = lambda qs: [(c.index, r) for c, r in qs]
+        return {
+            "k": k,
+            "num_fixed": self.num_fixed, "num_advice": self.num_advice, "num_instance": self.num_instance,
+            "blinding_factors": self.blinding_factors(), "cs_degree": self.degree(),
+            "advice_queries": cols(self.advice_queries), "fixed_queries": cols(self.fixed_queries),
+            "instance_queries": cols(self.instance_queries),
+            "gates": [g.to_tuple() for g in self.gates],
+            "lookups": [{"inputs": [e.to_tuple() for e in i], "tables": [e.to_tuple() for e in t]} for i, t in self.lookups],
+            "permutation_columns": [(c.kind, c.index) for c in self.permutation_columns],
+        }
+
+
+class Assembly:
+    """plonk::permutation::keygen::Assembly: the copy-constraint cycles. mapping[col][row] =
+    (col', row') with columns indexed by their position in `permutation_columns`."""
+
+    def __init__(self, n, ncols):
+        self.n, self.ncols = n, ncols
+        self.mapping = [[(c, r) for r in range(n)] for c in range(ncols)]
+        self.aux = [[(c, r) for r in range(n)] for c in range(ncols)]
+        self.sizes = [[1] * n for _ in range(ncols)]
+
+    def copy(self, lc, lr, rc, rr):
+        """Assembly::copy (upstream's union by size of two cycles)."""
+        left_cycle, right_cycle = self.aux[lc][lr], self.aux[rc][rr]
+        if left_cycle == right_cycle:
+            return
+        if self.sizes[left_cycle[0]][left_cycle[1]] < self.sizes[right_cycle[0]][right_cycle[1]]:
+            left_cycle, right_cycle = right_cycle, left_cycle
+        self.sizes[left_cycle[0]][left_cycle[1]] += self.sizes[right_cycle[0]][right_cycle[1]]
+        i, j = right_cycle
+        while True:
+            self.aux[i][j] = left_cycle
+            i, j = self.mapping[i][j]
+            if (i, j) == right_cycle:
+                break
+        tmp = self.mapping[lc][lr]
+        self.mapping[lc][lr] = self.mapping[rc][rr]
+        self.mapping[rc][rr] = tmp
+
+
+# ------------------------------------------------------------------------------------------------
+# Export to the C ABI (include/amdzk.h: amdzk_circuit) and the keygen / create_proof entry points.
+import ctypes as C  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+_XOP = {"const": 1, "fixed": 2, "advice": 3, "instance": 4, "neg": 5, "sum": 6, "product": 7, "scaled": 8}
+
+
+class _CCircuit(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("num_fixed", C.c_uint32), ("num_advice", C.c_uint32), ("num_instance", C.c_uint32),
+                ("blinding_factors", C.c_uint32), ("cs_degree", C.c_uint32),
+                ("num_advice_queries", C.c_uint32), ("advice_queries", C.c_void_p),
+                ("num_fixed_queries", C.c_uint32), ("fixed_queries", C.c_void_p),
+                ("num_instance_queries", C.c_uint32), ("instance_queries", C.c_void_p),
+                ("num_gates", C.c_uint32), ("num_lookups", C.c_uint32), ("num_exprs", C.c_uint32),
+                ("lookup_shape", C.c_void_p), ("expr_offsets", C.c_void_p), ("expr_words", C.c_void_p),
+                ("num_constants", C.c_uint32), ("constants", C.c_void_p),
+                ("num_perm_columns", C.c_uint32), ("perm_columns", C.c_void_p)]
+
+
+def _mont_limbs(v):
+    v = (v % R) * (1 << 256) % R
+    return [(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+
+
+def flatten_circuit(desc):
+    """describe() dict -> (amdzk_circuit, keepalive list)."""
+    consts, words, offsets = {}, [], [0]
+
+    def cidx(v):
+        return consts.setdefault(v % R, len(consts))
+
+    def emit(e):
+        op = e[0]
+        if op == "const":
+            words.append((_XOP[op] << 24) | cidx(e[1]))
+        elif op in ("fixed", "advice", "instance"):
+            assert -128 <= e[2] < 128 and e[1] < (1 << 16)
+            words.append((_XOP[op] << 24) | (e[1] << 8) | (e[2] + 128))
+        elif op == "neg":
+            emit(e[1])
+            words.append(_XOP[op] << 24)
+        elif op in ("sum", "product"):
+            emit(e[1])
+            emit(e[2])
+            words.append(_XOP[op] << 24)
+        elif op == "scaled":
+            emit(e[1])
+            words.append((_XOP[op] << 24) | cidx(e[2]))
+        else:
+            raise ValueError(op)
+
+    exprs = list(desc["gates"])
+    shape = []
+    for lk in desc["lookups"]:
+        shape += [len(lk["inputs"]), len(lk["tables"])]
+        exprs += list(lk["inputs"]) + list(lk["tables"])
+    for e in exprs:
+        emit(e)
+        offsets.append(len(words))
+    arrs = {
+        "aq": np.array(desc["advice_queries"], dtype=np.int32).reshape(-1, 2),
+        "fq": np.array(desc["fixed_queries"], dtype=np.int32).reshape(-1, 2),
+        "iq": np.array(desc["instance_queries"], dtype=np.int32).reshape(-1, 2),
+        "shape": np.array(shape, dtype=np.uint32),
+        "off": np.array(offsets, dtype=np.uint32),
+        "words": np.array(words, dtype=np.uint32),
+        "consts": np.array([_mont_limbs(v) for v, _ in sorted(consts.items(), key=lambda kv: kv[1])], dtype=np.uint64).reshape(-1, 4),
+        "perm": np.array(desc["permutation_columns"], dtype=np.uint32).reshape(-1, 2),
+    }
+    arrs = {k_: np.ascontiguousarray(v) for k_, v in arrs.items()}
+    p = lambda a: a.ctypes.data if a.size else None
+    c = _CCircuit(desc["k"], desc["num_fixed"], desc["num_advice"], desc["num_instance"], desc["blinding_factors"], desc["cs_degree"],
+                  len(arrs["aq"]), p(arrs["aq"]), len(arrs["fq"]), p(arrs["fq"]), len(arrs["iq"]), p(arrs["iq"]),
+                  len(desc["gates"]), len(desc["lookups"]), len(exprs), p(arrs["shape"]), p(arrs["off"]), p(arrs["words"]),
+                  len(arrs["consts"]), p(arrs["consts"]), len(arrs["perm"]), p(arrs["perm"]))
+    return c, arrs
+
+
+class ProvingKey:
+    """plonk::keygen::{keygen_vk, keygen_pk} result, resident on the device."""
+
+    def __init__(self, ctx, params, desc, fixed_values, mapping, transcript_repr):
+        """fixed_values: (num_fixed, n, 4) uint64 Montgomery; mapping: Assembly.mapping;
+        transcript_repr: (4,) uint64 Montgomery Fr."""
+        self.ctx, self.params, self.desc = ctx, params, desc
+        n = 1 << desc["k"]
+        cc, keep = flatten_circuit(desc)
+        fv = np.ascontiguousarray(fixed_values, dtype=np.uint64).reshape(desc["num_fixed"], n, 4) if desc["num_fixed"] else np.zeros((0, n, 4), np.uint64)
+        mp = np.ascontiguousarray(np.array(mapping, dtype=np.uint32).reshape(-1, n, 2)) if len(desc["permutation_columns"]) else np.zeros((0, n, 2), np.uint32)
+        tr = np.ascontiguousarray(transcript_repr, dtype=np.uint64).reshape(4)
+        h = C.c_void_p()
+        ctx._chk(ctx.L.amdzk_keygen(ctx.h, params.h, C.byref(cc), fv.ctypes.data if fv.size else None,
+                                    mp.ctypes.data if mp.size else None, tr.ctypes.data, C.byref(h)))
+        self.h = h
+        del keep
+
+    def commitments(self):
+        """(fixed_commitments, permutation_commitments) as (m, 8) uint64 affine points."""
+        f = np.zeros((self.desc["num_fixed"], 8), np.uint64)
+        p = np.zeros((len(self.desc["permutation_columns"]), 8), np.uint64)
+        self.ctx._chk(self.ctx.L.amdzk_pk_commitments(self.h, f.ctypes.data if f.size else None, p.ctypes.data if p.size else None))
+        return f, p
+
+    def free(self):
+        if self.h:
+            self.ctx.L.amdzk_pk_free(self.ctx.h, self.h)
+            self.h = None
+
+
+def create_proof(ctx, pk, instances, d_advice, seed, advice_stride=None):
+    """plonk::create_proof(params, pk, &[circuit], &[instances], ChaCha20Rng::seed_from_u64(seed), transcript).
+    instances: list of (len, 4) uint64 arrays; d_advice: DeviceBuffer (or anything with .ptr) holding
+    num_advice columns of n rows. Returns the proof bytes."""
+    n = 1 << pk.desc["k"]
+    cols = [np.ascontiguousarray(c, dtype=np.uint64).reshape(-1, 4) for c in instances]
+    ptrs = (C.c_void_p * max(1, len(cols)))(*[c.ctypes.data if c.size else None for c in cols])
+    lens = (C.c_size_t * max(1, len(cols)))(*[c.shape[0] for c in cols])
+    need = C.c_size_t(0)
+    cap = 1 << 20
+    buf = (C.c_uint8 * cap)()
+    ctx._chk(ctx.L.amdzk_create_proof(ctx.h, pk.h, ptrs, lens, d_advice.ptr if d_advice is not None else None, advice_stride or n,
+                                      C.c_uint64(seed), buf, cap, C.byref(need)))
+    return bytes(buf[: need.value])

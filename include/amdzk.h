@@ -136,6 +136,50 @@ int amdzk_extended_to_coeff_dev(amdzk_ctx* ctx, const amdzk_domain* dom, void* d
 int amdzk_divide_by_vanishing_dev(amdzk_ctx* ctx, const amdzk_domain* dom, void* d_ext, size_t ncols,
                                   size_t col_stride);
 
+/* ---- create_proof: replaces plonk::{keygen_pk, create_proof} [UP] for
+ * KZGCommitmentScheme<Bn256> + ProverSHPLONK + Blake2bWrite/Challenge255, one circuit instance,
+ * phase-0 advice. The circuit arrives as plain data: what ConstraintSystem holds after
+ * Circuit::configure (/root/reference/src/lib.rs:295-326 etc.) and selector compression.
+ *
+ * Expressions are postfix u32 words, op << 24 | payload:
+ *   1 CONST  payload = index into `constants`      2 FIXED / 3 ADVICE / 4 INSTANCE
+ *   5 NEG   6 ADD   7 MUL                              payload = column << 8 | (rotation + 128)
+ *   8 SCALE  payload = index into `constants` (multiply the top of stack by that constant)
+ * `expr_offsets[e] .. expr_offsets[e+1]` delimits expression e inside `expr_words`. The first
+ * num_gates expressions are the gate polynomials in order; then, per lookup l,
+ * lookup_shape[2l] input expressions followed by lookup_shape[2l+1] table expressions. */
+typedef struct amdzk_circuit {
+  uint32_t k, num_fixed, num_advice, num_instance, blinding_factors, cs_degree;
+  uint32_t num_advice_queries;   const int32_t* advice_queries;   /* (column, rotation) pairs, query order */
+  uint32_t num_fixed_queries;    const int32_t* fixed_queries;
+  uint32_t num_instance_queries; const int32_t* instance_queries;
+  uint32_t num_gates, num_lookups, num_exprs;
+  const uint32_t* lookup_shape;  /* 2 x num_lookups */
+  const uint32_t* expr_offsets;  /* num_exprs + 1 */
+  const uint32_t* expr_words;
+  uint32_t num_constants;        const uint64_t* constants;       /* Fr, Montgomery */
+  uint32_t num_perm_columns;     const uint32_t* perm_columns;    /* (kind: 0 advice 1 fixed 2 instance, index) */
+} amdzk_circuit;
+typedef struct amdzk_pk amdzk_pk;
+/* fixed_values: num_fixed x 2^k Fr (Lagrange, row-major per column). perm_mapping: for permutation
+ * column i and row j the pair (i', j') of permutation::keygen::Assembly::mapping, as
+ * perm_mapping[2*(i*n + j) + {0,1}]. transcript_repr: VerifyingKey::transcript_repr (upstream derives
+ * it from the Debug string of the pinned VK; the caller supplies it). The proving key owns the
+ * per-proof workspace: one proof at a time per key. */
+int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* circuit,
+                 const uint64_t* fixed_values, const uint32_t* perm_mapping,
+                 const uint64_t transcript_repr[4], amdzk_pk** out);
+void amdzk_pk_free(amdzk_ctx* ctx, amdzk_pk* pk);
+/* VerifyingKey commitments: fixed columns (num_fixed x G1Affine), permutation (num_perm_columns x G1Affine). */
+int amdzk_pk_commitments(const amdzk_pk* pk, uint64_t* fixed_out, uint64_t* perm_out);
+/* instances[c]: instance_lens[c] public inputs of instance column c (host). d_advice: num_advice
+ * witness columns of 2^k rows, device-resident, column c at d_advice + c*advice_stride (untouched:
+ * blinding happens on an internal copy). rng_seed: ChaCha20Rng::seed_from_u64(seed) drives every
+ * Fr::random draw in upstream order. proof_out may be NULL to query *proof_len. */
+int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances,
+                       const size_t* instance_lens, const void* d_advice, size_t advice_stride,
+                       uint64_t rng_seed, uint8_t* proof_out, size_t proof_cap, size_t* proof_len);
+
 /* ---- timing / profiling hooks used by bench.py (HIP events on this ctx's stream) ------------ */
 int amdzk_timer_start(amdzk_ctx* ctx);
 int amdzk_timer_stop(amdzk_ctx* ctx, float* ms); /* synchronises on the stop event */

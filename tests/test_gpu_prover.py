@@ -1,0 +1,106 @@
+"""GPU parity of the whole create_proof: the proof bytes produced on the MI355X equal, byte for byte,
+the bytes the pure-Python protocol oracle produces from the same circuit, witness, SRS and RNG seed
+(small k), and proofs of the full RSA-SHA256-shaped circuit at the reference's k = 15 are accepted by
+the oracle's verifier (vanishing identity + SHPLONK opening equation)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import zkutil as zu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import circuits  # noqa: E402
+import plonk_ref as PR  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TAU = 0x1234567890ABCDEF1234567
+
+
+@pytest.fixture(scope="module")
+def plonk(pkg):
+    return __import__("anon_aadhaar_halo2_amd.halo2.plonk", fromlist=["x"])
+
+
+_srs_cache = {}
+
+
+def setup(ctx, pkg, plonk, oracle, c, transcript_repr_int=123456789):
+    if c.k not in _srs_cache:
+        _srs_cache[c.k] = zu.test_srs(oracle, c.k, TAU)
+    g, gl = _srs_cache[c.k]
+    params = pkg.kzg.ParamsKZG(ctx, c.k, g=g, g_lagrange=gl)
+    fixed = np.stack([zu.ints_to_fr(oracle, col) for col in c.fixed]) if c.fixed else np.zeros((0, c.n, 4), np.uint64)
+    pk = plonk.ProvingKey(ctx, params, c.desc, fixed, c.assembly.mapping, zu.fr_from_int(transcript_repr_int))
+    adv = np.stack([zu.ints_to_fr(oracle, col) for col in c.advice])
+    d_adv = ctx.alloc(adv.nbytes).upload(adv)
+    inst = [zu.ints_to_fr(oracle, col) if col else np.zeros((0, 4), np.uint64) for col in c.instances]
+    return params, pk, d_adv, inst
+
+
+def vk_from_device(pk, c, transcript_repr_int=123456789):
+    f, p = pk.commitments()
+    return PR.VerifyingKey(c.desc, [zu.point_to_ints(x) for x in f], [zu.point_to_ints(x) for x in p], TAU, transcript_repr_int)
+
+
+@pytest.mark.parametrize("name,k", [("square", 4), ("square", 6), ("lookup", 5), ("lookup", 7)])
+def test_proof_bytes_equal_oracle(ctx, pkg, plonk, oracle, name, k):
+    c = circuits.square_circuit(plonk, k, signal=5) if name == "square" else circuits.lookup_circuit(plonk, k, seed=k)
+    params, pk, d_adv, inst = setup(ctx, pkg, plonk, oracle, c)
+    got = plonk.create_proof(ctx, pk, inst, d_adv, seed=99)
+    opk = PR.keygen(c.desc, c.fixed, c.assembly.mapping, TAU, transcript_repr=123456789)
+    # keygen parity: VK commitments computed on the device equal the oracle's
+    f, p = pk.commitments()
+    assert [zu.point_to_ints(x) for x in f] == opk.fixed_commitments
+    assert [zu.point_to_ints(x) for x in p] == opk.permutation_commitments
+    want = PR.create_proof(opk, c.instances, c.advice, seed=99)
+    assert got == want
+    assert PR.verify_proof(vk_from_device(pk, c), c.instances, got)
+    assert plonk.create_proof(ctx, pk, inst, d_adv, seed=99) == got  # workspace reuse is clean
+    assert plonk.create_proof(ctx, pk, inst, d_adv, seed=100) != got
+    d_adv.free(); pk.free(); params.free()
+
+
+def test_unsatisfied_witness_does_not_verify(ctx, pkg, plonk, oracle):
+    c = circuits.lookup_circuit(plonk, 6, seed=3)
+    c.advice[2][0] = (c.advice[2][0] + 1) % zu.R  # break the first mul gate
+    params, pk, d_adv, inst = setup(ctx, pkg, plonk, oracle, c)
+    proof = plonk.create_proof(ctx, pk, inst, d_adv, seed=5)
+    with pytest.raises(AssertionError):
+        PR.verify_proof(vk_from_device(pk, c), c.instances, proof)
+    d_adv.free(); pk.free(); params.free()
+
+
+def test_lookup_failure_is_reported(ctx, pkg, plonk, oracle):
+    c = circuits.lookup_circuit(plonk, 5, seed=4)
+    rows = [r for r in range(c.usable) if c.fixed[2][r] == 1]  # fixed[2] = q_rng: range lookup enabled
+    c.advice[0][rows[0]] = 9  # not in the 0..7 range table
+    params, pk, d_adv, inst = setup(ctx, pkg, plonk, oracle, c)
+    with pytest.raises(pkg.AmdzkError) as e:
+        plonk.create_proof(ctx, pk, inst, d_adv, seed=5)
+    assert "not in table" in str(e.value)
+    d_adv.free(); pk.free(); params.free()
+
+
+def test_rsa_sha256_shape_small_equals_oracle(ctx, pkg, plonk, oracle):
+    c = circuits.rsa_sha256_shape(plonk, k=7, num_advice=5, num_lookup_advice=2, lookup_bits=5, num_spread=2, spread_bits=3)
+    circuits.check_satisfied(c)
+    params, pk, d_adv, inst = setup(ctx, pkg, plonk, oracle, c)
+    got = plonk.create_proof(ctx, pk, inst, d_adv, seed=7)
+    opk = PR.keygen(c.desc, c.fixed, c.assembly.mapping, TAU, transcript_repr=123456789)
+    assert got == PR.create_proof(opk, c.instances, c.advice, seed=7)
+    assert PR.verify_proof(vk_from_device(pk, c), c.instances, got)
+    d_adv.free(); pk.free(); params.free()
+
+
+def test_rsa_sha256_shape_k15_verifies(ctx, pkg, plonk, oracle):
+    """Full budget of TestRSASignatureWithHashCircuit1 (/root/reference/src/lib.rs:263-274) at the
+    reference's k = 15: 112 advice, 24 lookups, 115 permutation columns."""
+    c = circuits.rsa_sha256_shape(plonk, k=15)
+    circuits.check_satisfied(c, rows=range(0, c.usable, 997))
+    assert c.desc["num_advice"] == 112 and len(c.desc["lookups"]) == 24 and len(c.desc["permutation_columns"]) == 115
+    params, pk, d_adv, inst = setup(ctx, pkg, plonk, oracle, c)
+    proof = plonk.create_proof(ctx, pk, inst, d_adv, seed=2024)
+    assert PR.verify_proof(vk_from_device(pk, c), c.instances, proof)
+    d_adv.free(); pk.free(); params.free()

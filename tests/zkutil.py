@@ -263,3 +263,32 @@ def jac_to_affine_host(oracle, jac):
         assert np.array_equal(j[8:], one), "result not normalised (z != 1)"
         out[i] = j[:8]
     return out[0] if out.shape[0] == 1 else out
+
+
+# ------------------------------------------------------------------------------ prover test plumbing
+def ints_to_fr(oracle, xs):
+    """Python ints (canonical) -> (len,4) uint64 Montgomery, via the oracle's from_raw (fast path)."""
+    raw = np.zeros((len(xs), 4), dtype=np.uint64)
+    mask = (1 << 64) - 1
+    for i, x in enumerate(xs):
+        if x:
+            raw[i, 0] = x & mask
+            raw[i, 1] = (x >> 64) & mask
+            raw[i, 2] = (x >> 128) & mask
+            raw[i, 3] = x >> 192
+    return oracle.fr_from_raw(raw)
+
+
+def test_srs(oracle, k, tau_int):
+    """g[i] = tau^i G and g_lagrange[i] = L_i(tau) G for a known tau (ParamsKZG::setup's values [UP])."""
+    n = 1 << k
+    g = oracle.srs_powers(fr_from_int(tau_int), n)
+    w = fr_to_int(oracle.omega(k))
+    tn1 = (pow(tau_int, n, R) - 1) % R
+    ninv = pow(n, -1, R)
+    scal, wi = [], 1
+    for i in range(n):
+        scal.append(wi * tn1 % R * ninv % R * pow((tau_int - wi) % R, -1, R) % R)
+        wi = wi * w % R
+    gl = oracle.g1_mul_many(oracle.generator(), ints_to_fr(oracle, scal))
+    return g, gl
