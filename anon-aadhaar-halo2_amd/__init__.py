@@ -10,4 +10,5 @@ repository's name); import it with `__graft_entry__.load_package()` which regist
 `anon_aadhaar_halo2_amd`.
 """
 from .ffi import AmdzkError, Context, lib, lib_path  # noqa: F401
+from . import batch  # noqa: F401
 from .halo2 import arithmetic, domain, kzg, plonk  # noqa: F401

@@ -14,6 +14,11 @@ void zk_srs_free(amdzk_ctx*, amdzk_srs* s);
 int zk_msm_dev_xyzz(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const Fr* d_scalars, size_t ncols,
                     size_t len, size_t col_stride, G1X** d_out);
 int zk_msm_finish(amdzk_ctx* ctx, const G1X* d_res, size_t ncols, uint64_t* out_jac);
+int zk_srs_setup(amdzk_ctx* ctx, uint32_t k, const uint64_t s_mont[4], const uint64_t omega_mont[4], amdzk_srs** out, uint64_t* g_out,
+                 uint64_t* g_lagrange_out);
+extern "C" int amdzk_domain_new(amdzk_ctx* ctx, uint32_t j, uint32_t k, struct amdzk_domain** out);
+extern "C" void amdzk_domain_free(amdzk_ctx* ctx, struct amdzk_domain* d);
+extern "C" int amdzk_domain_constant(const struct amdzk_domain* d, int what, uint64_t out[4]);
 
 static thread_local std::string g_init_err;
 
@@ -171,6 +176,16 @@ int amdzk_dev_memset(amdzk_ctx* ctx, void* dptr, int byte, size_t bytes) {
 int amdzk_srs_upload(amdzk_ctx* ctx, const uint64_t* g, const uint64_t* g_lagrange, uint32_t k, amdzk_srs** out) {
   if (!ctx) return AMDZK_E_INVALID;
   return zk_srs_upload(ctx, g, g_lagrange, k, out);
+}
+int amdzk_srs_setup(amdzk_ctx* ctx, uint32_t k, const uint64_t s[4], amdzk_srs** out, uint64_t* g_out, uint64_t* g_lagrange_out) {
+  if (!ctx) return AMDZK_E_INVALID;
+  if (!s || !out) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_setup: null argument");
+  amdzk_domain* dom = nullptr;
+  ZK_TRY(amdzk_domain_new(ctx, 3, k, &dom));
+  uint64_t omega[4];
+  amdzk_domain_constant(dom, 0, omega);
+  amdzk_domain_free(ctx, dom);
+  return zk_srs_setup(ctx, k, s, omega, out, g_out, g_lagrange_out);
 }
 void amdzk_srs_free(amdzk_ctx* ctx, amdzk_srs* srs) {
   if (ctx) hipStreamSynchronize(ctx->stream);

@@ -360,16 +360,15 @@ int launch_digits(amdzk_ctx* ctx, uint32_t c, const DigitArgs& a, dim3 grid) {
 }  // namespace
 
 // ---------------------------------------------------------------------------------- host side
-int zk_srs_upload(amdzk_ctx* ctx, const uint64_t* g, const uint64_t* g_lagrange, uint32_t k,
-                  amdzk_srs** out) {
-  if (!out || (!g && !g_lagrange)) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_upload: null argument");
-  if (k > 26) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "srs_upload: k %u > 26", k);
+static int srs_build(amdzk_ctx* ctx, const void* g, const void* g_lagrange, bool src_on_device, uint32_t k, amdzk_srs** out) {
+  if (!out || (!g && !g_lagrange)) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs: null argument");
+  if (k > 26) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "srs: k %u > 26", k);
   amdzk_srs* s = new amdzk_srs();
   s->k = k;
   s->n = (size_t)1 << k;
   s->c = pick_window_bits(k);
   s->W = (255 + s->c - 1) / s->c;
-  const uint64_t* src[2] = {g, g_lagrange};
+  const void* src[2] = {g, g_lagrange};
   for (int b = 0; b < 2; b++) {
     if (!src[b]) continue;
     size_t bytes = (size_t)s->W * s->n * sizeof(G1Affine);
@@ -378,17 +377,143 @@ int zk_srs_upload(amdzk_ctx* ctx, const uint64_t* g, const uint64_t* g_lagrange,
       for (int j = 0; j < 2; j++)
         if (s->table[j]) hipFree(s->table[j]);
       delete s;
-      ZK_FAIL(ctx, AMDZK_E_NOMEM, "srs_upload: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+      ZK_FAIL(ctx, AMDZK_E_NOMEM, "srs: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     }
-    ZK_HIP(ctx, hipMemcpyAsync(s->table[b], src[b], s->n * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipMemcpyAsync(s->table[b], src[b], s->n * sizeof(G1Affine), src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                               ctx->stream));
     dim3 grid((unsigned)((s->n + 255) / 256)), block(256);
     for (uint32_t w = 1; w < s->W; w++)
       ZK_LAUNCH(ctx, "msm_table_next", table_next_kernel, grid, block, 0, s->table[b] + (size_t)(w - 1) * s->n,
                 s->table[b] + (size_t)w * s->n, s->n, s->c);
   }
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host source buffers may be released by the caller
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // source buffers may be released by the caller
   *out = s;
   return AMDZK_OK;
+}
+
+int zk_srs_upload(amdzk_ctx* ctx, const uint64_t* g, const uint64_t* g_lagrange, uint32_t k, amdzk_srs** out) {
+  return srs_build(ctx, g, g_lagrange, false, k, out);
+}
+
+// ---- ParamsKZG::setup(k, rng) [UP] with the secret s given explicitly (unsafe by construction, test
+// and benchmark use only, exactly like upstream's setup): g[i] = s^i G, g_lagrange[i] = L_i(s) G with
+// L_i(s) = omega^i (s^n - 1) / (n (s - omega^i)). Everything on the device.
+namespace {
+// out[i] = sum over set bits j of the canonical scalar of table[j] (table[j] = 2^j G), affine.
+__global__ __launch_bounds__(256) void fixed_base_mul_kernel(const Fr* scalars, const G1Affine* table, G1Affine* out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4* sp = reinterpret_cast<const uint4*>(scalars + i);
+  uint4 lo = sp[0], hi = sp[1];
+  Fr s;
+  s.l[0] = lo.x; s.l[1] = lo.y; s.l[2] = lo.z; s.l[3] = lo.w;
+  s.l[4] = hi.x; s.l[5] = hi.y; s.l[6] = hi.z; s.l[7] = hi.w;
+  Fr c = from_mont(s);
+  G1X acc = G1X::inf();
+#pragma unroll 1
+  for (int limb = 0; limb < 8; limb++) {
+    uint32_t w = c.l[limb];
+#pragma unroll 1
+    for (int b = 0; b < 32; b++)
+      if ((w >> b) & 1) acc = x_add_affine(acc, ld_aff(table + limb * 32 + b));
+  }
+  st_aff(out + i, x_to_affine(acc));
+}
+// p[i] = base^i
+__global__ void powers_kernel(Fr* p, Fr base, size_t count, uint32_t chunk) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t start = t * chunk;
+  if (start >= count) return;
+  Fr cur = pow_u64(base, start);
+  size_t end = start + chunk < count ? start + chunk : count;
+  for (size_t i = start; i < end; i++) {
+    uint4* q = reinterpret_cast<uint4*>(p + i);
+    q[0] = make_uint4(cur.l[0], cur.l[1], cur.l[2], cur.l[3]);
+    q[1] = make_uint4(cur.l[4], cur.l[5], cur.l[6], cur.l[7]);
+    cur = mul(cur, base);
+  }
+}
+// den[i] = s - w[i]
+__global__ void sub_from_const_kernel(Fr* den, const Fr* w, Fr s, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4* q = reinterpret_cast<const uint4*>(w + i);
+  uint4 a = q[0], b = q[1];
+  Fr v;
+  v.l[0] = a.x; v.l[1] = a.y; v.l[2] = a.z; v.l[3] = a.w;
+  v.l[4] = b.x; v.l[5] = b.y; v.l[6] = b.z; v.l[7] = b.w;
+  Fr r = sub(s, v);
+  uint4* o = reinterpret_cast<uint4*>(den + i);
+  o[0] = make_uint4(r.l[0], r.l[1], r.l[2], r.l[3]);
+  o[1] = make_uint4(r.l[4], r.l[5], r.l[6], r.l[7]);
+}
+// a[i] = a[i] * w[i] * c
+__global__ void mul2_kernel(Fr* a, const Fr* w, Fr c, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4* q = reinterpret_cast<const uint4*>(w + i);
+  uint4 x0 = q[0], x1 = q[1];
+  Fr v;
+  v.l[0] = x0.x; v.l[1] = x0.y; v.l[2] = x0.z; v.l[3] = x0.w;
+  v.l[4] = x1.x; v.l[5] = x1.y; v.l[6] = x1.z; v.l[7] = x1.w;
+  const uint4* p = reinterpret_cast<const uint4*>(a + i);
+  uint4 y0 = p[0], y1 = p[1];
+  Fr u;
+  u.l[0] = y0.x; u.l[1] = y0.y; u.l[2] = y0.z; u.l[3] = y0.w;
+  u.l[4] = y1.x; u.l[5] = y1.y; u.l[6] = y1.z; u.l[7] = y1.w;
+  Fr r = mul(mul(u, v), c);
+  uint4* o = reinterpret_cast<uint4*>(a + i);
+  o[0] = make_uint4(r.l[0], r.l[1], r.l[2], r.l[3]);
+  o[1] = make_uint4(r.l[4], r.l[5], r.l[6], r.l[7]);
+}
+}  // namespace
+
+int zk_batch_invert(amdzk_ctx* ctx, Fr* d_a, Fr* d_scratch, size_t total);
+
+int zk_srs_setup(amdzk_ctx* ctx, uint32_t k, const uint64_t s_mont[4], const uint64_t omega_mont[4], amdzk_srs** out,
+                 uint64_t* g_out, uint64_t* g_lagrange_out) {
+  if (k > 26) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "srs_setup: k %u > 26", k);
+  const size_t n = (size_t)1 << k;
+  Fr s, omega;
+  memcpy(s.l, s_mont, 32);
+  memcpy(omega.l, omega_mont, 32);
+  // workspace (slot 3): gtable[256] | scal[n] | w[n] | scratch[n] | g[n] | gl[n]
+  char* ws = nullptr;
+  const size_t bytes = 256 * sizeof(G1Affine) + 3 * n * sizeof(Fr) + 2 * n * sizeof(G1Affine);
+  ZK_TRY(zk_ws_reserve(ctx, 3, bytes, (void**)&ws));
+  G1Affine* gtab = (G1Affine*)ws;
+  Fr* scal = (Fr*)(ws + 256 * sizeof(G1Affine));
+  Fr* w = scal + n;
+  Fr* scratch = w + n;
+  G1Affine* g = (G1Affine*)(scratch + n);
+  G1Affine* gl = g + n;
+  {  // 2^j G on the host (256 doublings)
+    std::vector<G1Affine> t(256);
+    G1Affine gen;
+    gen.x = Fq::one();
+    gen.y = add(Fq::one(), Fq::one());
+    t[0] = gen;
+    for (int j = 1; j < 256; j++) t[j] = x_to_affine(x_dbl_affine(t[j - 1]));
+    ZK_HIP(ctx, hipMemcpyAsync(gtab, t.data(), 256 * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  const uint32_t chunk = 64;
+  dim3 pg((unsigned)(((n + chunk - 1) / chunk + 63) / 64)), pb(64);
+  dim3 eg((unsigned)((n + 255) / 256)), eb(256);
+  ZK_LAUNCH(ctx, "srs_powers", powers_kernel, pg, pb, 0, scal, s, n, chunk);
+  ZK_LAUNCH(ctx, "srs_fixed_base_mul", fixed_base_mul_kernel, eg, eb, 0, scal, gtab, g, n);
+  // Lagrange scalars
+  ZK_LAUNCH(ctx, "srs_powers", powers_kernel, pg, pb, 0, w, omega, n, chunk);
+  ZK_LAUNCH(ctx, "srs_sub", sub_from_const_kernel, eg, eb, 0, scal, w, s, n);
+  ZK_TRY(zk_batch_invert(ctx, scal, scratch, n));
+  Fr two = add(Fr::one(), Fr::one());
+  Fr mult = mul(sub(pow_u64(s, n), Fr::one()), inv(pow_u64(two, k)));  // (s^n - 1) / n
+  ZK_LAUNCH(ctx, "srs_mul2", mul2_kernel, eg, eb, 0, scal, w, mult, n);
+  ZK_LAUNCH(ctx, "srs_fixed_base_mul", fixed_base_mul_kernel, eg, eb, 0, scal, gtab, gl, n);
+  if (g_out) ZK_HIP(ctx, hipMemcpyAsync(g_out, g, n * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream));
+  if (g_lagrange_out) ZK_HIP(ctx, hipMemcpyAsync(g_lagrange_out, gl, n * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return srs_build(ctx, g, gl, true, k, out);
 }
 
 void zk_srs_free(amdzk_ctx*, amdzk_srs* s) {

@@ -41,6 +41,7 @@ def lib():
         "amdzk_dev_download": (i32, [vp, vp, vp, sz]),
         "amdzk_dev_memset": (i32, [vp, vp, i32, sz]),
         "amdzk_srs_upload": (i32, [vp, vp, vp, u32, C.POINTER(vp)]),
+        "amdzk_srs_setup": (i32, [vp, u32, vp, C.POINTER(vp), vp, vp]),
         "amdzk_srs_free": (None, [vp, vp]),
         "amdzk_msm_g1": (i32, [vp, vp, i32, vp, sz, vp]),
         "amdzk_msm_g1_batch": (i32, [vp, vp, i32, C.POINTER(vp), sz, sz, vp]),

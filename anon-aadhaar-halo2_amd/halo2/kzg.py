@@ -25,6 +25,21 @@ class ParamsKZG:
                                         None if g_lagrange is None else _ptr(self._gl), k, C.byref(h)))
         self.h = h
 
+    @classmethod
+    def setup(cls, ctx, k, s, want_host_copy=False):
+        """ParamsKZG::setup(k, rng) with the trapdoor `s` ((4,) uint64 Montgomery Fr) given explicitly
+        (test / benchmark SRS, as unsafe as upstream's setup). Bases are generated on the device."""
+        self = cls.__new__(cls)
+        self.ctx, self.k, self.n = ctx, k, 1 << k
+        s = np.ascontiguousarray(s, dtype=np.uint64).reshape(4)
+        self._g = np.zeros((self.n, 8), np.uint64) if want_host_copy else None
+        self._gl = np.zeros((self.n, 8), np.uint64) if want_host_copy else None
+        h = C.c_void_p()
+        ctx._chk(ctx.L.amdzk_srs_setup(ctx.h, k, _ptr(s), C.byref(h), None if self._g is None else _ptr(self._g),
+                                       None if self._gl is None else _ptr(self._gl)))
+        self.h = h
+        return self
+
     def commit(self, poly_coeff):
         """ParamsKZG::commit(poly, _blind): MSM with g[..len] (the blind is ignored for KZG)."""
         return arithmetic.best_multiexp(self.ctx, self.h, BASIS_G, poly_coeff)

@@ -1,20 +1,19 @@
 #!/usr/bin/env python3
-"""bench.py — proofs/s of the create_proof hot path on MI355X (contract: see the task brief).
+"""bench.py — create_proof throughput on MI355X (contract: see the task brief).
 
-One "step" = the device work of ONE proof of the RSA-SHA256 circuit shape
-(/root/reference/src/lib.rs:263-274,295-326: k=15, 80 gate advice + 16 range-lookup advice +
-16 SHA spread advice, 24 lookups, 115 permutation columns -> 58 permutation products, degree 4 so
-extended_k = 17), on synthetic witness columns already resident in HBM:
-  * 248 MSMs of 2^15   (112 advice + 48 permuted lookup columns + 82 grand products + 1 random +
-                        3 quotient pieces + 2 SHPLONK openings), batched per protocol phase,
-  * 244 iNTTs of 2^15  (lagrange_to_coeff of every committed column),
-  * 244 coset NTTs 2^15 -> 2^17 (coeff_to_extended) and 1 extended iNTT (extended_to_coeff).
-This is the round-1 workload ("proof_shape_proxy"): the quotient evaluation, grand products,
-evaluations and the Fiat-Shamir host driver are not yet inside the step, and `config.workload`
-says so. Nothing in the timed region is cached: every step recomputes every MSM and NTT.
+One "step" = ONE full `create_proof` (KZG/SHPLONK/Blake2b, halo2_proofs v2023_01_20 semantics) of the
+RSA-SHA256 circuit shape of the reference (/root/reference/src/lib.rs:263-274,295-326: k = 15,
+80 vertical-gate advice + 16 range-lookup advice + 16 SHA spread advice columns, 24 lookups,
+115 permutation columns -> 58 grand products, degree 4 so extended_k = 17), on a synthetic satisfying
+witness that is already resident in HBM when the timed region starts. Each step
+draws fresh blinding (seed = step index) and recomputes everything: 248 MSMs, 244 iNTTs, 244 coset
+NTTs, the h(X) evaluation over 2^17 rows, 58+24 grand products, ~900 evaluations, SHPLONK. Witness
+synthesis (the reference's Rust chips) and keygen are outside the step, as in upstream's own split.
+The SRS is a real one (g[i] = s^i G, g_lagrange[i] = L_i(s) G, built on the device), so the proofs are
+valid; tests/test_gpu_prover.py verifies this same circuit's proof with the oracle's verifier.
 
 N > 1: independent proofs shard one-per-GPU (weak scaling); the only collective is the gather of
-the finished commitments (RCCL all_gather of fixed-size byte strings).
+the finished proof bytes (fixed length), an RCCL all_gather.
 """
 import argparse
 import json
@@ -26,41 +25,42 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-K = 15
-N_ADVICE, N_LOOKUP_PERM, N_PRODUCTS, N_G_BASIS = 112, 48, 82, 6
-N_POLYS = N_ADVICE + N_LOOKUP_PERM + N_PRODUCTS + 2  # + 2 instance columns
 HBM_PEAK_GBS = 8000.0
+R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 
-
-def make_columns(torch, ctx, ncols, n, kind, seed):
-    """Synthetic witness columns on the device, Montgomery form (BASELINE.md §3 distributions)."""
-    g = torch.Generator(device="cuda")
-    g.manual_seed(seed)
-    a = torch.randint(0, 2 ** 62, (ncols, n, 4), dtype=torch.int64, device="cuda", generator=g)
-    a[..., 3] >>= 2  # < 2^60 < top limb of r: a valid canonical value
-    if kind == "uniform":
-        return a  # any value < r is a valid Montgomery representation of a uniform element
-    sel = torch.randint(0, 10, (ncols, n), device="cuda", generator=g)
-    small = sel < 7
-    zero = (sel >= 7) & (sel < 9)
-    if kind == "lookup":  # permuted lookup columns: table-sized values (12-bit range table)
-        a[..., 0] &= 0xFFF
-        a[..., 1:] = 0
-    else:  # witness-like: 70% < 2^64, 20% zero, 10% uniform
-        a[..., 1:][small] = 0
-        a[zero] = 0
-    ctx._chk(ctx.L.amdzk_fr_from_raw_dev(ctx.h, a.data_ptr(), a.numel() // 4))  # canonical -> Montgomery
-    ctx.sync()
-    return a
+SHAPES = {
+    # the reference's own configuration (src/lib.rs:263-274, k = 15 at src/lib.rs:444)
+    "k15": dict(k=15, num_advice=80, num_lookup_advice=16, lookup_bits=12, num_spread=8, spread_bits=8),
+    # BASELINE.json configs[1] "k~18": same area, 8x fewer gate columns
+    "k18": dict(k=18, num_advice=10, num_lookup_advice=2, lookup_bits=12, num_spread=1, spread_bits=8),
+}
 
 
 class DevView:
-    """Lets pkg helpers address a torch tensor's storage."""
-
-    def __init__(self, t):
+    def __init__(self, ptr):
         import ctypes
-        self.ptr = ctypes.c_void_p(t.data_ptr())
+        self.ptr = ctypes.c_void_p(ptr)
+
+
+def canon_limbs(cols):
+    """list of columns of Python ints -> (ncols, n, 4) uint64 canonical limbs."""
+    out = np.zeros((len(cols), len(cols[0]), 4), dtype=np.uint64)
+    mask = (1 << 64) - 1
+    for c, col in enumerate(cols):
+        small = all(v < (1 << 63) for v in col)
+        if small:
+            out[c, :, 0] = np.array(col, dtype=np.uint64)
+            continue
+        for i, v in enumerate(col):
+            if v:
+                out[c, i, 0] = v & mask
+                if v >> 64:
+                    out[c, i, 1] = (v >> 64) & mask
+                    out[c, i, 2] = (v >> 128) & mask
+                    out[c, i, 3] = v >> 192
+    return out
 
 
 def main():
@@ -68,6 +68,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--shape", default="k15", choices=sorted(SHAPES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -75,66 +76,61 @@ def main():
     import torch.distributed as dist
 
     import __graft_entry__ as ge
+    import circuits
 
     pkg = ge.load_package()
+    plonk = pkg.plonk
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a gfx950 GPU (no CPU fallback in the product path)")
+        raise SystemExit("bench.py needs a gfx950 GPU (there is no CPU fallback in the product path)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = pkg.Context(local_rank)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # one stream for torch copies and amdzk kernels
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    shape = SHAPES[args.shape]
+    K = shape["k"]
     n = 1 << K
+    t_setup = time.perf_counter()
+    c = circuits.rsa_sha256_shape(plonk, seed=7 + rank, **shape)
+    desc = c.desc
 
-    # ---- SRS: synthetic bases. Any set of curve points exercises the same arithmetic; take
-    # pseudo-random multiples of the generator made by the device itself (MSM of unit vectors would
-    # be circular), here: small-multiple ladder i*G via repeated addition on the host is too slow,
-    # so use the oracle-free closed form: hash-to-x + square-root on the host with python ints.
-    bases = synth_bases(2 * n, seed=7)
-    params = pkg.kzg.ParamsKZG(ctx, K, g=bases[:n].copy(), g_lagrange=bases[n:].copy())
-    dom = pkg.domain.EvaluationDomain(ctx, 4, K)
-    en = dom.extended_len()
-
-    adv = make_columns(torch, ctx, N_ADVICE, n, "witness", 1 + rank)
-    lkp = make_columns(torch, ctx, N_LOOKUP_PERM, n, "lookup", 2 + rank)
-    prod = make_columns(torch, ctx, N_PRODUCTS + N_G_BASIS + 2, n, "uniform", 3 + rank)
-    coeff = torch.empty((N_POLYS, n, 4), dtype=torch.int64, device="cuda")
-    ext = torch.empty((N_POLYS, en, 4), dtype=torch.int64, device="cuda")
-    hq = torch.randint(0, 2 ** 60, (1, en, 4), dtype=torch.int64, device="cuda")
-    torch.cuda.synchronize()
-
-    A = pkg.arithmetic
-    commits = {}
-
-    def step():
-        # phase 1-3: commitments (Lagrange basis), one batched submission per protocol phase
-        commits["advice"] = A.best_multiexp_dev(ctx, params.h, 1, DevView(adv), N_ADVICE, n)
-        commits["lookup"] = A.best_multiexp_dev(ctx, params.h, 1, DevView(lkp), N_LOOKUP_PERM, n)
-        commits["products"] = A.best_multiexp_dev(ctx, params.h, 1, DevView(prod), N_PRODUCTS, n)
-        # lagrange -> coeff of every committed column (+ instance), then to the extended coset
-        coeff[:N_ADVICE].copy_(adv)
-        coeff[N_ADVICE:N_ADVICE + N_LOOKUP_PERM].copy_(lkp)
-        coeff[N_ADVICE + N_LOOKUP_PERM:].copy_(prod[:N_PRODUCTS + 2])
-        dom.lagrange_to_coeff_dev(DevView(coeff), ncols=N_POLYS)
-        dom.coeff_to_extended_dev(DevView(coeff), DevView(ext), ncols=N_POLYS)
-        # quotient: /Z_H, back to coefficients, commit random + 3 pieces + 2 openings (monomial basis)
-        dom.divide_by_vanishing_poly_dev(DevView(hq))
-        dom.extended_to_coeff_dev(DevView(hq))
-        commits["g"] = A.best_multiexp_dev(ctx, params.h, 0, DevView(prod[N_PRODUCTS + 2:]), N_G_BASIS, n)
+    def to_mont_dev(cols):
+        lim = canon_limbs(cols)
+        t = torch.from_numpy(lim.view(np.int64)).cuda()
+        ctx._chk(ctx.L.amdzk_fr_from_raw_dev(ctx.h, t.data_ptr(), t.numel() // 4))
         ctx.sync()
+        return t
 
-    for _ in range(args.warmup):
-        step()
+    s_int = 0x0123456789ABCDEF0123456789ABCDEF % R
+    s_mont = np.array([((s_int << 256) % R >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+    params = pkg.kzg.ParamsKZG.setup(ctx, K, s_mont)
+    fixed_host = to_mont_dev(c.fixed).cpu().numpy().view(np.uint64)
+    tr = np.array([1, 2, 3, 4], dtype=np.uint64)
+    pk = plonk.ProvingKey(ctx, params, desc, fixed_host, c.assembly.mapping, tr)
+    adv = to_mont_dev(c.advice)  # resident witness, (A, n, 4)
+    inst = [to_mont_dev([col]).cpu().numpy().view(np.uint64)[0] if col else np.zeros((0, 4), np.uint64) for col in c.instances]
+    d_adv = DevView(adv.data_ptr())
+    t_setup = time.perf_counter() - t_setup
+
+    proofs = []
+
+    def step(i):
+        proofs.append(plonk.create_proof(ctx, pk, inst, d_adv, seed=1000 * rank + i))
+
+    for i in range(args.warmup):
+        step(i)
+    proofs.clear()
     ctx.sync()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(args.warmup + i)
     ctx.sync()
     torch.cuda.synchronize()
     if world > 1:
@@ -144,124 +140,102 @@ def main():
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        # the one exchange step: gather every rank's commitments (fixed-size byte strings) on all ranks
-        blob = torch.from_numpy(np.concatenate([commits[k].reshape(-1) for k in sorted(commits)]).view(np.int64)).cuda()
-        out = [torch.empty_like(blob) for _ in range(world)]
-        dist.all_gather(out, blob)
+        # the one exchange step: every rank's proofs (equal length) gathered on all ranks over RCCL.
+        # global proof index = step*world + rank (round-robin, batch.shard_indices)
+        gathered = pkg.batch.gather_proofs(proofs, world * args.steps, device="cuda")
+        assert len(gathered) == world * args.steps and all(len(p) == len(proofs[0]) for p in gathered)
 
-    # ---- roofline of the dominant kernel, measured live with HIP events on the ctx stream
-    roof = None
-    cpu = None
+    roof = cpu = None
     if rank == 0:
+        # per-kernel timing of one more proof with HIP events on the ctx stream
         ctx.prof_reset()
         ctx.prof_enable(True)
-        step()
+        t1 = time.perf_counter()
+        step(10 ** 6)
+        wall_prof = (time.perf_counter() - t1) * 1e3
         ctx.prof_enable(False)
         prof = ctx.prof_dump()
         dom_name = max(prof, key=lambda kname: prof[kname][1])
         launches, total_ms = prof[dom_name]
-        step_ms = sum(v[1] for v in prof.values())
-        # algorithmic bytes of one MSM = 96*n (32 B scalar + 64 B base); this step's msm_accum_l1
-        # launches cover (112, 48, 82, 6) columns -> mean columns per launch:
-        cols_per_launch = (N_ADVICE + N_LOOKUP_PERM + N_PRODUCTS + N_G_BASIS) / 4.0
+        gpu_ms = sum(v[1] for v in prof.values())
+        A, L, S = desc["num_advice"], len(desc["lookups"]), len(desc["permutation_columns"])
+        nsets = (S + desc["cs_degree"] - 3) // (desc["cs_degree"] - 2)
+        msm_cols = A + 2 * L + nsets + L + 1 + (desc["cs_degree"] - 1) + 2
+        npolys = A + desc["num_instance"] + 3 * L + nsets
         if dom_name.startswith("msm"):
-            alg_bytes = 96.0 * n * cols_per_launch
-        else:
-            alg_bytes = 64.0 * n * N_POLYS
+            # algorithmic bytes of an MSM = 96 B per (scalar, base) pair; this kernel's
+            # launches cover all msm_cols committed columns of the proof
+            alg_bytes = 96.0 * n * msm_cols / launches
+        elif dom_name.startswith("ntt"):
+            alg_bytes = 64.0 * (n * npolys + (n << 2) * npolys + (n << 2)) / launches
+        else:  # h(X) evaluation: every coset column read once + h written
+            alg_bytes = 32.0 * (n << 2) * (npolys + desc["num_fixed"] + S + 4 + 1) / launches
         avg_s = total_ms / launches * 1e-3
         roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(alg_bytes / avg_s / 1e9, 3), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
                 "avg_launch_ms": round(total_ms / launches, 4), "launches_per_step": launches,
-                "kernel_share_of_step": round(total_ms / step_ms, 3),
+                "gpu_busy_ms_per_step": round(gpu_ms, 3), "wall_ms_profiled_step": round(wall_prof, 3),
                 "per_kernel_ms": {kname: round(v[1], 3) for kname, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
         if not args.no_cpu_baseline:
-            cpu = cpu_baseline(adv, lkp, prod, bases, n)
+            cpu = cpu_baseline(adv, K, msm_cols, npolys)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
-        line = {"metric": "create_proof proofs/sec (device work of one proof, RSA-SHA256 circuit shape k=15)",
+        line = {"metric": "create_proof wall-clock (ms) + proofs/sec, RSA-SHA256 circuit shape",
                 "value": round(world * args.steps / dt, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "u32x8 (254-bit Montgomery integers)", "data": "synthetic",
-                "config": {"workload": "proof_shape_proxy: rsa_sha256 shape k=15 — 248 MSM(2^15) + 244 iNTT(2^15) + "
-                                       "244 coset NTT(2^15->2^17) + 1 extended iNTT; quotient evaluation, grand products, "
-                                       "evaluations and transcript NOT yet in the step",
-                           "k": K, "extended_k": dom.extended_k, "proofs_per_gpu_per_step": 1, "parallelism": "proofs sharded 1/GPU"},
+                "config": {"workload": "create_proof, rsa_sha256_shape %s: %d advice, %d lookups, %d permutation columns, degree %d, "
+                                       "KZG/SHPLONK/Blake2b, witness resident, lookup permutation on host (next row)"
+                                       % (args.shape, desc["num_advice"], len(desc["lookups"]), len(desc["permutation_columns"]), desc["cs_degree"]),
+                           "k": K, "extended_k": K + 2, "proof_bytes": len(proofs[-1]), "proofs_per_gpu_per_step": 1,
+                           "parallelism": "independent proofs sharded 1/GPU", "setup_s_excluded": round(t_setup, 1)},
                 "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+    pk.free()
     params.free()
-    dom.free()
     ctx.close()
 
 
-def synth_bases(count, seed):
-    """Deterministic curve points: x from splitmix64, y = sqrt(x^3+3) (q = 3 mod 4), Montgomery form.
-    Pure python integers; ~20 us per point."""
-    q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
-    mont = (1 << 256) % q
-    out = np.zeros((count, 8), dtype=np.uint64)
-    s = seed & 0xFFFFFFFFFFFFFFFF
-    i = 0
-
-    def nxt():
-        nonlocal s
-        s = (s + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
-        z = s
-        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
-        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
-        return z ^ (z >> 31)
-
-    while i < count:
-        x = (nxt() | (nxt() << 64) | (nxt() << 128) | ((nxt() >> 3) << 192)) % q
-        rhs = (x * x * x + 3) % q
-        y = pow(rhs, (q + 1) // 4, q)
-        if y * y % q != rhs:
-            continue
-        xm, ym = x * mont % q, y * mont % q
-        for l in range(4):
-            out[i, l] = (xm >> (64 * l)) & 0xFFFFFFFFFFFFFFFF
-            out[i, 4 + l] = (ym >> (64 * l)) & 0xFFFFFFFFFFFFFFFF
-        i += 1
-    return out
-
-
-def cpu_baseline(adv, lkp, prod, bases, n):
-    """CPU leg: the oracle (port of halo2's best_multiexp / best_fft, OpenMP over all host cores) on a
-    bounded sample of the same step: 6 MSMs (2 per column kind), 4 iNTT 2^15, 4 coset NTT 2^17; scaled
-    to the step's counts. The oracle is only the measured baseline here, never the product path."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+def cpu_baseline(adv, K, msm_cols, npolys):
+    """CPU leg: the oracle (C++ restatement of halo2's best_multiexp / best_fft, OpenMP) on a bounded
+    sample of one proof's MSM/NTT list — 4 MSMs on real witness columns, 2 on uniform columns, 4 iNTT,
+    4 coset NTT — scaled to the proof's counts. It covers ONLY the MSM/NTT part of create_proof
+    (no quotient evaluation, grand products or openings), so it understates the CPU prover's time.
+    The oracle is the measured baseline here, never the product path."""
     import zkutil as zu
 
     O = zu.Oracle()
-    cores = O.threads
-    gl = bases[n:]
+    n = 1 << K
+    bases = O.srs_powers(zu.fr_from_int(12345), 1 << 10)
+    bases = np.ascontiguousarray(np.tile(bases, (n >> 10, 1)))  # timing only: any on-curve points
 
-    def t_msm(t):
-        col = np.ascontiguousarray(t.cpu().numpy().view(np.uint64))
+    def t_msm(col):
         t0 = time.perf_counter()
-        O.best_multiexp(col, gl)
+        O.best_multiexp(np.ascontiguousarray(col), bases)
         return time.perf_counter() - t0
 
-    m_adv = (t_msm(adv[0]) + t_msm(adv[1])) / 2
-    m_lkp = (t_msm(lkp[0]) + t_msm(lkp[1])) / 2
-    m_uni = (t_msm(prod[0]) + t_msm(prod[1])) / 2
+    wit = [adv[i].cpu().numpy().view(np.uint64) for i in (0, 1, adv.shape[0] - 1, adv.shape[0] - 20)]
+    m_wit = sum(t_msm(w) for w in wit) / len(wit)
+    m_uni = sum(t_msm(zu.random_fr(n, seed=s)) for s in (1, 2)) / 2
     od = zu.OracleDomain(O, 4, K)
-    cols = [np.ascontiguousarray(prod[i].cpu().numpy().view(np.uint64)) for i in range(4)]
+    cols = [zu.random_fr(n, seed=10 + s) for s in range(4)]
     t0 = time.perf_counter()
-    for c in cols:
-        od.lagrange_to_coeff(c)
+    for col in cols:
+        od.lagrange_to_coeff(col)
     t_intt = (time.perf_counter() - t0) / 4
     t0 = time.perf_counter()
-    for c in cols:
-        od.coeff_to_extended(c)
+    for col in cols:
+        od.coeff_to_extended(col)
     t_ext = (time.perf_counter() - t0) / 4
-    per_proof = (N_ADVICE * m_adv + N_LOOKUP_PERM * m_lkp + (N_PRODUCTS + N_G_BASIS) * m_uni + N_POLYS * (t_intt + t_ext) + t_ext)
-    return {"value": round(1.0 / per_proof, 5), "unit": "proofs/s", "cores": cores, "kind": "port",
-            "sample": "6 MSM(2^15) + 4 iNTT(2^15) + 4 coset NTT(2^17) timed with the C++ oracle (OpenMP, %d threads), "
-                      "scaled to the step's 248/244/245 counts" % cores,
-            "ms_per_msm": {"witness": round(m_adv * 1e3, 2), "lookup": round(m_lkp * 1e3, 2), "uniform": round(m_uni * 1e3, 2)},
+    a_cols = adv.shape[0]
+    per_proof = a_cols * m_wit + (msm_cols - a_cols) * m_uni + npolys * (t_intt + t_ext) + t_ext
+    return {"value": round(1.0 / per_proof, 5), "unit": "proofs/s", "cores": O.threads, "kind": "port",
+            "sample": "MSM+NTT portion only: 4 witness-column MSMs + 2 uniform MSMs + 4 iNTT + 4 coset NTT at k=%d with the C++ "
+                      "oracle (OpenMP, %d threads), scaled to the proof's %d MSMs / %d polynomials" % (K, O.threads, msm_cols, npolys),
+            "ms_per_msm": {"witness": round(m_wit * 1e3, 2), "uniform": round(m_uni * 1e3, 2)},
             "ms_per_intt": round(t_intt * 1e3, 2), "ms_per_coset_ntt": round(t_ext * 1e3, 2)}
 
 

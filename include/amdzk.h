@@ -78,6 +78,11 @@ int amdzk_dev_memset(amdzk_ctx* ctx, void* dptr, int byte, size_t bytes);
  * (2^(c*w) * g[i]) so that every MSM is bucket-accumulation only (MSM). */
 int amdzk_srs_upload(amdzk_ctx* ctx, const uint64_t* g, const uint64_t* g_lagrange, uint32_t k,
                      amdzk_srs** out);
+/* ParamsKZG::setup(k, rng) [UP] with the trapdoor s supplied by the caller (as unsafe as upstream's
+ * setup: tests and benchmarks only): g[i] = s^i G, g_lagrange[i] = L_i(s) G, built on the device.
+ * g_out / g_lagrange_out (2^k G1Affine each, host) may be NULL. */
+int amdzk_srs_setup(amdzk_ctx* ctx, uint32_t k, const uint64_t s[4], amdzk_srs** out, uint64_t* g_out,
+                    uint64_t* g_lagrange_out);
 void amdzk_srs_free(amdzk_ctx* ctx, amdzk_srs* srs);
 
 /* ---- MSM: replaces arithmetic::best_multiexp(coeffs, bases) as called from

@@ -109,3 +109,20 @@ def test_msm_linearity_large(ctx, pkg, oracle):
     assert np.array_equal(got, want)
     assert np.array_equal(got, oracle.best_multiexp(s, g))
     params.free()
+
+
+def test_srs_setup_on_device_matches_oracle(ctx, pkg, oracle):
+    """amdzk_srs_setup (ParamsKZG::setup with an explicit trapdoor) against the oracle's tau-powers and
+    closed-form Lagrange bases; then commit_lagrange(p) == commit(lagrange_to_coeff(p))."""
+    k, tau = 10, 0x1234567890ABCDEF1234567
+    n = 1 << k
+    params = pkg.kzg.ParamsKZG.setup(ctx, k, zu.fr_from_int(tau), want_host_copy=True)
+    g, gl = zu.test_srs(oracle, k, tau)
+    assert np.array_equal(params._g, g)
+    assert np.array_equal(params._gl, gl)
+    p = zu.random_fr(n, seed=31)
+    od = zu.OracleDomain(oracle, 3, k)
+    a = zu.jac_to_affine_host(oracle, params.commit_lagrange(p))
+    b = zu.jac_to_affine_host(oracle, params.commit(od.lagrange_to_coeff(p)))
+    assert np.array_equal(a, b) and np.array_equal(a, oracle.best_multiexp(p, gl))
+    params.free()
