@@ -304,6 +304,142 @@ __global__ __launch_bounds__(1024) void kate_div_kernel(Fr* const* polys, const 
   }
 }
 
+
+// ------------------------------------------------------------------------------ lookup permutation
+// plonk::lookup::prover::permute_expression_pair on the device: keys are
+// canonical field elements (numeric order = upstream's Ord for Fr), sorted by a bitonic network —
+// LDS-resident for strides inside a 2048-element tile, one global pass per larger stride.
+constexpr uint32_t SORT_TILE = 2048;
+
+__device__ __forceinline__ bool key_less(const Fr& a, const Fr& b) {
+#pragma unroll
+  for (int i = 7; i >= 0; i--) {
+    if (a.l[i] != b.l[i]) return a.l[i] < b.l[i];
+  }
+  return false;
+}
+__device__ __forceinline__ bool key_eq(const Fr& a, const Fr& b) { return a == b; }
+
+// k_from..k_to (inclusive, powers of two): runs every (k, j) step with j < SORT_TILE inside LDS.
+// full = 1: k from 2 (local sort of each tile); full = 0: only the j < SORT_TILE tail of stage k_to.
+__global__ __launch_bounds__(1024) void bitonic_lds_kernel(Fr* data, size_t col_stride, uint32_t n, uint32_t k_from, uint32_t k_to) {
+  extern __shared__ uint4 lds_raw[];
+  Fr* L = reinterpret_cast<Fr*>(lds_raw);
+  const uint32_t tile = n < SORT_TILE ? n : SORT_TILE;
+  const uint32_t base = blockIdx.x * tile, t = threadIdx.x;
+  Fr* col = data + (size_t)blockIdx.y * col_stride;
+  for (uint32_t i = t; i < tile; i += blockDim.x) L[i] = ld_fr(col + base + i);
+  __syncthreads();
+  for (uint32_t k = k_from; k <= k_to; k <<= 1) {
+    uint32_t jstart = k >> 1;
+    if (jstart >= tile) jstart = tile >> 1;
+    for (uint32_t j = jstart; j >= 1; j >>= 1) {
+      for (uint32_t p = t; p < (tile >> 1); p += blockDim.x) {
+        uint32_t i = ((p / j) * 2 * j) + (p % j), l = i + j;
+        bool asc = (((base + i) & k) == 0);
+        Fr a = L[i], b = L[l];
+        bool sw = asc ? key_less(b, a) : key_less(a, b);
+        if (sw) {
+          L[i] = b;
+          L[l] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (uint32_t i = t; i < tile; i += blockDim.x) st_fr(col + base + i, L[i]);
+}
+
+__global__ __launch_bounds__(256) void bitonic_global_kernel(Fr* data, size_t col_stride, uint32_t n, uint32_t k, uint32_t j) {
+  Fr* col = data + (size_t)blockIdx.y * col_stride;
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (n >> 1)) return;
+  uint32_t i = ((p / j) * 2 * j) + (p % j), l = i + j;
+  bool asc = ((i & k) == 0);
+  Fr a = ld_fr(col + i), b = ld_fr(col + l);
+  bool sw = asc ? key_less(b, a) : key_less(a, b);
+  if (sw) {
+    st_fr(col + i, b);
+    st_fr(col + l, a);
+  }
+}
+
+// For each row r < u of the sorted input A: rep[r] = 1 if A[r] == A[r-1]; otherwise claim the first
+// table position holding that value (used[p] = 1), or raise *err if the value is not in the table.
+__global__ __launch_bounds__(256) void lookup_mark_kernel(const Fr* A, const Fr* Ts, size_t col_stride, uint32_t u, uint32_t* rep,
+                                                          uint32_t* used, size_t flag_stride, int* err) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, lk = blockIdx.y;
+  if (r >= u) return;
+  const Fr* a = A + (size_t)lk * col_stride;
+  const Fr* ts = Ts + (size_t)lk * col_stride;
+  Fr v = ld_fr(a + r);
+  bool first = r == 0 || !key_eq(ld_fr(a + r - 1), v);
+  rep[(size_t)lk * flag_stride + r] = first ? 0u : 1u;
+  if (!first) return;
+  uint32_t lo = 0, hi = u;  // lowest p with ts[p] >= v
+  while (lo < hi) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (key_less(ld_fr(ts + mid), v)) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= u || !key_eq(ld_fr(ts + lo), v)) {
+    atomicExch(err, (int)lk + 1);
+    return;
+  }
+  used[(size_t)lk * flag_stride + lo] = 1u;
+}
+
+// out[i] = number of set (invert = 0) / clear (invert = 1) flags before i, i < cnt; out[cnt] = total.
+__global__ __launch_bounds__(1024) void flag_scan_kernel(const uint32_t* flags, uint32_t* out, uint32_t cnt, size_t stride, int invert) {
+  __shared__ uint32_t part[1024];
+  const uint32_t t = threadIdx.x;
+  const uint32_t* f = flags + (size_t)blockIdx.x * stride;
+  uint32_t* o = out + (size_t)blockIdx.x * stride;
+  const uint32_t per = (cnt + 1023) / 1024, b0 = t * per, b1 = min(b0 + per, cnt);
+  uint32_t sum = 0;
+  for (uint32_t b = b0; b < b1; b++) sum += invert ? (f[b] ? 0u : 1u) : (f[b] ? 1u : 0u);
+  part[t] = sum;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    uint32_t v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[t] - sum;
+  for (uint32_t b = b0; b < b1; b++) {
+    o[b] = run;
+    run += invert ? (f[b] ? 0u : 1u) : (f[b] ? 1u : 0u);
+  }
+  if (t == 1023) o[cnt] = part[1023];
+}
+
+// left[rank] = Ts[p] for every unclaimed table position p (ascending).
+__global__ __launch_bounds__(256) void lookup_compact_kernel(const Fr* Ts, size_t col_stride, uint32_t u, const uint32_t* used,
+                                                             const uint32_t* rank_left, size_t flag_stride, Fr* left) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x, lk = blockIdx.y;
+  if (p >= u) return;
+  if (used[(size_t)lk * flag_stride + p]) return;
+  st_fr(left + (size_t)lk * col_stride + rank_left[(size_t)lk * flag_stride + p], ld_fr(Ts + (size_t)lk * col_stride + p));
+}
+
+// S[r] = A[r] on first occurrences; repeated rows take the leftovers, ascending leftovers to
+// descending rows (upstream pops repeated rows from the back while walking the BTreeMap upwards).
+__global__ __launch_bounds__(256) void lookup_assign_kernel(const Fr* A, const Fr* left, Fr* S, size_t col_stride, uint32_t u,
+                                                            const uint32_t* rep, const uint32_t* rank_rep, const uint32_t* rank_left,
+                                                            size_t flag_stride, int* err) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x, lk = blockIdx.y;
+  if (r >= u) return;
+  const size_t fo = (size_t)lk * flag_stride, co = (size_t)lk * col_stride;
+  const uint32_t R = rank_rep[fo + u];
+  if (r == 0 && R != rank_left[fo + u]) atomicExch(err, (int)lk + 1);  // multiset sizes must agree
+  if (!rep[fo + r]) {
+    st_fr(S + co + r, ld_fr(A + co + r));
+  } else {
+    uint32_t k = R - 1 - rank_rep[fo + r];
+    st_fr(S + co + r, ld_fr(left + co + k));
+  }
+}
+
 // dst[col][row0 + i] = src[col][i], i < cnt   (blinding rows from a packed host upload)
 __global__ void scatter_rows_kernel(Fr* dst, size_t col_stride, size_t row0, const Fr* src, uint32_t cnt, uint32_t ncols) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -391,5 +527,42 @@ int zk_kate_div(amdzk_ctx* ctx, Fr* const* d_polys, const Fr* d_roots, size_t np
 int zk_scatter_rows(amdzk_ctx* ctx, Fr* d_dst, size_t col_stride, size_t row0, const Fr* d_src, uint32_t cnt, uint32_t ncols) {
   uint32_t total = cnt * ncols;
   if (total) ZK_LAUNCH(ctx, "scatter_rows", scatter_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, d_dst, col_stride, row0, d_src, cnt, ncols);
+  return AMDZK_OK;
+}
+
+// Sort ncols columns of n (power of two) canonical keys ascending, in place.
+int zk_sort_keys(amdzk_ctx* ctx, Fr* d_cols, size_t ncols, uint32_t n, size_t col_stride) {
+  if (ncols == 0 || n < 2) return AMDZK_OK;
+  const uint32_t tile = n < SORT_TILE ? n : SORT_TILE;
+  const size_t shmem = (size_t)tile * sizeof(Fr);
+  const unsigned threads = tile / 2 >= 1024 ? 1024 : (tile / 2 >= 64 ? tile / 2 : 64);
+  if (shmem > 65536) ZK_HIP(ctx, hipFuncSetAttribute((const void*)bitonic_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  ZK_LAUNCH(ctx, "sort_bitonic_lds", bitonic_lds_kernel, dim3(n / tile, (unsigned)ncols), dim3(threads), shmem, d_cols, col_stride, n, 2u, tile);
+  for (uint32_t k = tile << 1; k <= n && k != 0; k <<= 1) {
+    for (uint32_t j = k >> 1; j >= tile; j >>= 1)
+      ZK_LAUNCH(ctx, "sort_bitonic_global", bitonic_global_kernel, dim3((n / 2 + 255) / 256, (unsigned)ncols), dim3(256), 0, d_cols, col_stride, n, k, j);
+    ZK_LAUNCH(ctx, "sort_bitonic_lds", bitonic_lds_kernel, dim3(n / tile, (unsigned)ncols), dim3(threads), shmem, d_cols, col_stride, n, k, k);
+  }
+  return AMDZK_OK;
+}
+
+// permute_expression_pair for L lookups: A (sorted inputs, in place), Ts (sorted tables), S out.
+// flags: 4 u32 arrays of flag_stride per lookup: rep | used | rank_rep | rank_left (flag_stride >= u+1).
+int zk_lookup_permute(amdzk_ctx* ctx, Fr* A, Fr* Ts, Fr* S, Fr* left, size_t L, uint32_t n, uint32_t u, uint32_t* flags, size_t flag_stride,
+                      int* d_err) {
+  if (L == 0) return AMDZK_OK;
+  uint32_t* rep = flags;
+  uint32_t* used = flags + L * flag_stride;
+  uint32_t* rank_rep = flags + 2 * L * flag_stride;
+  uint32_t* rank_left = flags + 3 * L * flag_stride;
+  ZK_TRY(zk_sort_keys(ctx, A, L, n, n));
+  ZK_TRY(zk_sort_keys(ctx, Ts, L, n, n));
+  ZK_HIP(ctx, hipMemsetAsync(flags, 0, 2 * L * flag_stride * sizeof(uint32_t), ctx->stream));
+  dim3 grid((u + 255) / 256, (unsigned)L), block(256);
+  ZK_LAUNCH(ctx, "lookup_mark", lookup_mark_kernel, grid, block, 0, A, Ts, (size_t)n, u, rep, used, flag_stride, d_err);
+  ZK_LAUNCH(ctx, "lookup_flag_scan", flag_scan_kernel, dim3((unsigned)L), dim3(1024), 0, rep, rank_rep, u, flag_stride, 0);
+  ZK_LAUNCH(ctx, "lookup_flag_scan", flag_scan_kernel, dim3((unsigned)L), dim3(1024), 0, used, rank_left, u, flag_stride, 1);
+  ZK_LAUNCH(ctx, "lookup_compact", lookup_compact_kernel, grid, block, 0, Ts, (size_t)n, u, used, rank_left, flag_stride, left);
+  ZK_LAUNCH(ctx, "lookup_assign", lookup_assign_kernel, grid, block, 0, A, left, S, (size_t)n, u, rep, rank_rep, rank_left, flag_stride, d_err);
   return AMDZK_OK;
 }

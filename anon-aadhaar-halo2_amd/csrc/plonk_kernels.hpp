@@ -50,3 +50,6 @@ int zk_sub_low(amdzk_ctx* ctx, bn254::Fr* d_a, const bn254::Fr* d_low, uint32_t 
 int zk_kate_div(amdzk_ctx* ctx, bn254::Fr* const* d_polys, const bn254::Fr* d_roots, size_t npolys, uint32_t n);
 int zk_scatter_rows(amdzk_ctx* ctx, bn254::Fr* d_dst, size_t col_stride, size_t row0, const bn254::Fr* d_src, uint32_t cnt,
                     uint32_t ncols);
+int zk_sort_keys(amdzk_ctx* ctx, bn254::Fr* d_cols, size_t ncols, uint32_t n, size_t col_stride);
+int zk_lookup_permute(amdzk_ctx* ctx, bn254::Fr* A, bn254::Fr* Ts, bn254::Fr* S, bn254::Fr* left, size_t L, uint32_t n, uint32_t u,
+                      uint32_t* flags, size_t flag_stride, int* d_err);

@@ -11,14 +11,16 @@
 // kernel on resident columns: all committed columns of a phase go through ONE batched MSM, all
 // polynomials through ONE batched iNTT and ONE batched coset NTT, and the whole h(X) numerator is
 // ONE interpreter launch. Host<->device traffic per proof: the blinding scalars and the random
-// polynomial up (n*32 B), commitments and evaluations down — except the lookup permutation, which
-// round 1 still does on the host (next row).
+// polynomial up (n*32 B), commitments and evaluations down. The lookup permutation
+// (permute_expression_pair) also runs on the device (bitonic sort of the
+// canonical values + multiset alignment).
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <array>
-#include <thread>
+#include <chrono>
+#include <map>
 
 #include "hostcrypto.hpp"
 #include "plonk_kernels.hpp"
@@ -120,6 +122,9 @@ struct amdzk_pk {
   Fr *ci = nullptr, *ct = nullptr;  // [L][n] compressed lookup input / table
   Fr *rnd = nullptr, *hq = nullptr, *hpoly = nullptr, *frac = nullptr, *scratch = nullptr, *scan_tmp = nullptr;
   Fr *sets_L = nullptr, *sets_N = nullptr, *hx = nullptr;  // SHPLONK buffers
+  Fr *lk_ts = nullptr, *lk_left = nullptr;  // lookup permutation: sorted tables, leftovers [L][n]
+  uint32_t* lk_flags = nullptr;              // [4][L][n+8]
+  int* d_err = nullptr;
   Fr* small = nullptr;  // misc small device buffer (blinding uploads, points, evals, coefs)
   void* ptrs = nullptr;  // device pointer-table scratch
   size_t small_cap = 0, ptrs_cap = 0;
@@ -134,6 +139,9 @@ struct amdzk_pk {
   Fr** d_outs_pfrac = nullptr;
   Fr** d_outs_lfrac = nullptr;
   std::vector<void*> allocs;
+  // pinned host staging (bump allocator, reset whenever the stream is known to be idle)
+  char* pin = nullptr;
+  size_t pin_cap = 0, pin_off = 0;
 
   Fr* adv() { return P; }
   Fr* inst() { return P + (size_t)A * n; }
@@ -179,6 +187,21 @@ int dalloc(amdzk_ctx* ctx, amdzk_pk* pk, T** p, size_t count) {
 
 int h2d(amdzk_ctx* ctx, void* d, const void* h, size_t bytes) {
   if (bytes) ZK_HIP(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return AMDZK_OK;
+}
+// host -> device through the key's pinned staging area: the source may be a temporary, and the copy
+// is truly asynchronous (no pageable-memory staging inside the runtime).
+int h2d_staged(amdzk_ctx* ctx, amdzk_pk* pk, void* d, const void* h, size_t bytes) {
+  if (!bytes) return AMDZK_OK;
+  if (!pk->pin || bytes > pk->pin_cap) return h2d(ctx, d, h, bytes);
+  size_t off = (pk->pin_off + 63) & ~(size_t)63;
+  if (off + bytes > pk->pin_cap) {
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    off = 0;
+  }
+  memcpy(pk->pin + off, h, bytes);
+  pk->pin_off = off + bytes;
+  ZK_HIP(ctx, hipMemcpyAsync(d, pk->pin + off, bytes, hipMemcpyHostToDevice, ctx->stream));
   return AMDZK_OK;
 }
 int d2h(amdzk_ctx* ctx, void* h, const void* d, size_t bytes) {
@@ -336,36 +359,6 @@ void trace_pt(const char* label, const G1Affine& p) {
   fprintf(stderr, "\n");
 }
 
-// lookup::prover::permute_expression_pair on canonical values (host, one lookup)
-bool permute_pair(const std::array<uint64_t, 4>* inp, const std::array<uint64_t, 4>* tab, size_t usable, std::array<uint64_t, 4>* out_a,
-                  std::array<uint64_t, 4>* out_s) {
-  std::vector<std::array<uint64_t, 4>> a(inp, inp + usable), t(tab, tab + usable);
-  std::sort(a.begin(), a.end(), fr_less_canon);
-  std::sort(t.begin(), t.end(), fr_less_canon);
-  std::vector<uint8_t> used(usable, 0);
-  std::vector<size_t> repeated;
-  size_t tp = 0;
-  for (size_t row = 0; row < usable; row++) {
-    out_a[row] = a[row];
-    if (row == 0 || a[row] != a[row - 1]) {
-      while (tp < usable && fr_less_canon(t[tp], a[row])) tp++;
-      if (tp >= usable || t[tp] != a[row]) return false;  // input value not in the table
-      used[tp] = 1;
-      out_s[row] = a[row];
-      tp++;  // later distinct inputs are larger; duplicates of this value stay unmarked (leftovers)
-    } else {
-      repeated.push_back(row);
-    }
-  }
-  for (size_t i = 0; i < usable; i++) {  // leftovers ascending -> repeated rows from the back
-    if (used[i]) continue;
-    if (repeated.empty()) return false;
-    out_s[repeated.back()] = t[i];
-    repeated.pop_back();
-  }
-  return repeated.empty();
-}
-
 }  // namespace
 
 extern "C" {
@@ -374,6 +367,7 @@ void amdzk_pk_free(amdzk_ctx* ctx, amdzk_pk* pk) {
   if (!pk) return;
   if (ctx) hipStreamSynchronize(ctx->stream);
   for (void* p : pk->allocs) hipFree(p);
+  if (pk->pin) hipHostFree(pk->pin);
   if (pk->dom) amdzk_domain_free(ctx, pk->dom);
   delete pk;
 }
@@ -466,6 +460,10 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
   KG_TRY(dalloc(ctx, pk, &pk->PC, pk->NP * ext));
   KG_TRY(dalloc(ctx, pk, &pk->ci, (size_t)L * n));
   KG_TRY(dalloc(ctx, pk, &pk->ct, (size_t)L * n));
+  KG_TRY(dalloc(ctx, pk, &pk->lk_ts, (size_t)L * n));
+  KG_TRY(dalloc(ctx, pk, &pk->lk_left, (size_t)L * n));
+  KG_TRY(dalloc(ctx, pk, &pk->lk_flags, (size_t)4 * L * (n + 8)));
+  KG_TRY(dalloc(ctx, pk, &pk->d_err, 1));
   KG_TRY(dalloc(ctx, pk, &pk->rnd, n));
   KG_TRY(dalloc(ctx, pk, &pk->hq, ext));
   KG_TRY(dalloc(ctx, pk, &pk->hpoly, n));
@@ -479,6 +477,11 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
   KG_TRY(dalloc(ctx, pk, &pk->hx, n));
   pk->small_cap = std::max<size_t>((size_t)pk->NP * (pk->bf + 2) + 4096, 8192);
   KG_TRY(dalloc(ctx, pk, &pk->small, pk->small_cap));
+  pk->pin_cap = std::max<size_t>((size_t)8 << 20, 2 * n * 32);
+  if (hipHostMalloc((void**)&pk->pin, pk->pin_cap, hipHostMallocDefault) != hipSuccess) {
+    pk->pin = nullptr;
+    pk->pin_cap = 0;
+  }
   pk->ptrs_cap = 8192;
   {
     void** pp = nullptr;
@@ -848,9 +851,19 @@ int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* inst
   if (advice_stride < n) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: advice stride < n");
   ChaCha20Rng rng(rng_seed);
   Blake2bWrite T;
+  const bool ttrace = getenv("AMDZK_TRACE_TIME") != nullptr;
+  auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tlast = tnow();
+  auto tick = [&](const char* label) {
+    if (!ttrace) return;
+    hipStreamSynchronize(ctx->stream);
+    double t = tnow();
+    fprintf(stderr, "[amdzk-time] %-28s %8.3f ms\n", label, t - tlast);
+    tlast = t;
+  };
   auto upload_small = [&](const std::vector<Fr>& v, size_t off_elems) -> int {
     if (off_elems + v.size() > pk->small_cap) ZK_FAIL(ctx, AMDZK_E_NOMEM, "create_proof: small buffer overflow");
-    return h2d(ctx, pk->small + off_elems, v.data(), v.size() * 32);
+    return h2d_staged(ctx, pk, pk->small + off_elems, v.data(), v.size() * 32);
   };
   auto write_points = [&](const std::vector<G1Affine>& pts, const char* label) -> int {
     for (auto& p : pts) {
@@ -861,9 +874,8 @@ int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* inst
   };
   // blinding tails: draw cnt scalars per column (column-major draw order), scatter into rows [row0, row0+cnt)
   auto blind_rows = [&](Fr* d_cols, uint32_t ncols, size_t row0, uint32_t cnt, const std::vector<Fr>& vals) -> int {
-    ZK_TRY(upload_small(vals, 0));
+    ZK_TRY(upload_small(vals, 0));  // staged through pinned memory: `vals` may die right after
     ZK_TRY(zk_scatter_rows(ctx, d_cols, n, row0, pk->small, cnt, ncols));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `vals` is a host temporary
     return AMDZK_OK;
   };
 
@@ -893,37 +905,33 @@ int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* inst
     ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G_LAGRANGE, pk->adv(), A, cm));
     ZK_TRY(write_points(cm, "advice"));
   }
+  tick("advice");
   Fr theta = T.squeeze_challenge();
   trace_fr("theta", theta);
   pk->consts[pk->c_theta] = theta;
-  ZK_TRY(h2d(ctx, pk->d_consts + pk->c_theta, &pk->consts[pk->c_theta], 32));
+  ZK_TRY(h2d_staged(ctx, pk, pk->d_consts + pk->c_theta, &pk->consts[pk->c_theta], 32));
   // 2. lookups: compress, permute (host, round 1), blind, commit
   if (L) {
     ZK_TRY(run_program(ctx, pk, pk->prog_compress, false, pk->d_outs_compress, nullptr, "expr_lookup_compress"));
-    // canonical copies for sorting: scratch <- ci | ct, to_repr on device
-    std::vector<std::array<uint64_t, 4>> hin((size_t)L * n), htab((size_t)L * n), ha((size_t)L * n), hs((size_t)L * n);
+    // permute_expression_pair on the device: canonical keys, rows >= usable padded with an all-ones
+    // sentinel (> any canonical value) so the power-of-two sort leaves the real rows in front.
     ZK_TRY(d2d(ctx, pk->la(), pk->ci, (size_t)L * n * 32));
-    ZK_TRY(d2d(ctx, pk->ls(), pk->ct, (size_t)L * n * 32));
-    ZK_TRY(amdzk_fr_to_repr_dev(ctx, pk->la(), (size_t)2 * L * n));
-    ZK_TRY(d2h(ctx, hin.data(), pk->la(), (size_t)L * n * 32));
-    ZK_TRY(d2h(ctx, htab.data(), pk->ls(), (size_t)L * n * 32));
-    std::vector<int> ok(L, 1);
-    {
-      unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
-      nt = std::min<unsigned>(nt, L);
-      std::vector<std::thread> th;
-      for (unsigned t = 0; t < nt; t++)
-        th.emplace_back([&, t]() {
-          for (uint32_t l = t; l < L; l += nt)
-            ok[l] = permute_pair(&hin[(size_t)l * n], &htab[(size_t)l * n], usable, &ha[(size_t)l * n], &hs[(size_t)l * n]) ? 1 : 0;
-        });
-      for (auto& x : th) x.join();
-    }
-    for (uint32_t l = 0; l < L; l++)
-      if (!ok[l]) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: lookup %u input not in table (ConstraintSystemFailure)", l);
-    ZK_TRY(h2d(ctx, pk->la(), ha.data(), (size_t)L * n * 32));
-    ZK_TRY(h2d(ctx, pk->ls(), hs.data(), (size_t)L * n * 32));
+    ZK_TRY(d2d(ctx, pk->lk_ts, pk->ct, (size_t)L * n * 32));
+    ZK_TRY(amdzk_fr_to_repr_dev(ctx, pk->la(), (size_t)L * n));
+    ZK_TRY(amdzk_fr_to_repr_dev(ctx, pk->lk_ts, (size_t)L * n));
+    ZK_HIP(ctx, hipMemset2DAsync(pk->la() + usable, n * 32, 0xFF, (n - usable) * 32, L, ctx->stream));
+    ZK_HIP(ctx, hipMemset2DAsync(pk->lk_ts + usable, n * 32, 0xFF, (n - usable) * 32, L, ctx->stream));
+    ZK_HIP(ctx, hipMemsetAsync(pk->d_err, 0, sizeof(int), ctx->stream));
+    ZK_TRY(zk_lookup_permute(ctx, pk->la(), pk->lk_ts, pk->ls(), pk->lk_left, L, (uint32_t)n, (uint32_t)usable, pk->lk_flags, n + 8, pk->d_err));
+    ZK_HIP(ctx, hipMemset2DAsync(pk->la() + usable, n * 32, 0, (n - usable) * 32, L, ctx->stream));
+    ZK_HIP(ctx, hipMemset2DAsync(pk->ls() + usable, n * 32, 0, (n - usable) * 32, L, ctx->stream));
     ZK_TRY(amdzk_fr_from_raw_dev(ctx, pk->la(), (size_t)2 * L * n));
+    {
+      int herr = 0;
+      ZK_TRY(d2h(ctx, &herr, pk->d_err, sizeof(int)));
+      if (herr) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: lookup %d input not in table (ConstraintSystemFailure)", herr - 1);
+    }
+    tick("  lookup: device permute");
     // RNG order per lookup: a' tail, s' tail, blind(a'), blind(s')
     std::vector<Fr> ta((size_t)L * (bf + 1)), ts((size_t)L * (bf + 1));
     for (uint32_t l = 0; l < L; l++) {
@@ -941,6 +949,7 @@ int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* inst
       ZK_TRY(write_points(two, "lookup_permuted"));
     }
   }
+  tick("lookups_permuted");
   Fr beta = T.squeeze_challenge();
   Fr gamma = T.squeeze_challenge();
   trace_fr("beta", beta);
@@ -953,25 +962,31 @@ int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* inst
       pk->consts[pk->c_bdelta + j] = cur;
       cur = mul(cur, delta);
     }
-    ZK_TRY(h2d(ctx, pk->d_consts + pk->c_beta, &pk->consts[pk->c_beta], (size_t)(pk->consts.size() - pk->c_beta) * 32));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_TRY(h2d_staged(ctx, pk, pk->d_consts + pk->c_beta, &pk->consts[pk->c_beta], (size_t)(pk->consts.size() - pk->c_beta) * 32));
   }
   // 3. permutation grand products
+  tick("  perm: challenges+consts");
   if (ns) {
     ZK_TRY(run_program(ctx, pk, pk->prog_pfrac, false, pk->d_outs_pfrac, nullptr, "expr_perm_fractions"));
+    tick("  perm: fractions program");
     ZK_TRY(zk_batch_invert(ctx, pk->frac, pk->scratch, (size_t)ns * n));
+    tick("  perm: batch invert");
     ZK_TRY(zk_mul_elem(ctx, pk->zp(), pk->frac, (size_t)ns * n));
+    tick("  perm: fractions+invert");
     ZK_TRY(zk_running_product(ctx, pk->zp(), ns, n, n, true, usable, pk->scan_tmp));
+    tick("  perm: running product");
     std::vector<Fr> tail((size_t)ns * bf);
     for (uint32_t s = 0; s < ns; s++) {
       for (uint32_t i = 0; i < bf; i++) tail[(size_t)s * bf + i] = rng.fr();
       (void)rng.fr();
     }
     ZK_TRY(blind_rows(pk->zp(), ns, n - bf, bf, tail));
+    tick("  perm: blind");
     std::vector<G1Affine> cm;
     ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G_LAGRANGE, pk->zp(), ns, cm));
     ZK_TRY(write_points(cm, "perm_z"));
   }
+  tick("perm_products");
   // 4. lookup grand products
   if (L) {
     ZK_TRY(run_program(ctx, pk, pk->prog_lfrac, false, pk->d_outs_lfrac, nullptr, "expr_lookup_fractions"));
@@ -988,24 +1003,27 @@ int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* inst
     ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G_LAGRANGE, pk->zl(), L, cm));
     ZK_TRY(write_points(cm, "lookup_z"));
   }
+  tick("lookup_products");
   // 5. vanishing: random polynomial (coefficient form), commit with g
   {
     std::vector<Fr> rp(n);
     for (auto& v : rp) v = rng.fr();
     (void)rng.fr();
-    ZK_TRY(h2d(ctx, pk->rnd, rp.data(), n * 32));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    tick("  random: host rng");
+    ZK_TRY(h2d_staged(ctx, pk, pk->rnd, rp.data(), n * 32));
     std::vector<G1Affine> cm;
     ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G, pk->rnd, 1, cm));
     ZK_TRY(write_points(cm, "random_poly"));
   }
+  tick("random_poly");
   Fr y = T.squeeze_challenge();
   trace_fr("y", y);
   pk->consts[pk->c_y] = y;
-  ZK_TRY(h2d(ctx, pk->d_consts + pk->c_y, &pk->consts[pk->c_y], 32));
+  ZK_TRY(h2d_staged(ctx, pk, pk->d_consts + pk->c_y, &pk->consts[pk->c_y], 32));
   // 6. every committed column: Lagrange -> coefficients -> extended coset; then h(X)
   ZK_TRY(amdzk_lagrange_to_coeff_dev(ctx, pk->dom, pk->P, pk->NP, n));
   ZK_TRY(amdzk_coeff_to_extended_dev(ctx, pk->dom, pk->P, n, pk->PC, ext, pk->NP));
+  tick("intt+coset_ntt");
   ZK_TRY(run_program(ctx, pk, pk->prog_h, true, nullptr, pk->hq, "expr_evaluate_h"));
   ZK_TRY(amdzk_divide_by_vanishing_dev(ctx, pk->dom, pk->hq, 1, ext));
   ZK_TRY(amdzk_extended_to_coeff_dev(ctx, pk->dom, pk->hq, 1, ext));
@@ -1015,6 +1033,7 @@ int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* inst
     ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G, pk->hq, pk->qdeg, cm));  // pieces are consecutive n-blocks of hq
     ZK_TRY(write_points(cm, "h_piece"));
   }
+  tick("h_eval+commit");
   Fr x = T.squeeze_challenge();
   trace_fr("x", x);
   Fr xn = pow_u64(x, n);
@@ -1028,10 +1047,9 @@ int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* inst
       cf[i] = cur;
       cur = mul(cur, xn);
     }
-    ZK_TRY(h2d(ctx, pk->ptrs, pp.data(), pp.size() * sizeof(Fr*)));
+    ZK_TRY(h2d_staged(ctx, pk, pk->ptrs, pp.data(), pp.size() * sizeof(Fr*)));
     ZK_TRY(upload_small(cf, 0));
     ZK_TRY(zk_lincomb(ctx, (const Fr* const*)pk->ptrs, pk->small, pk->qdeg, pk->hpoly, n, false));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   // 7. evaluations. One list of (polynomial, rotation) in proof order, then the two extra
   //    evaluations SHPLONK needs (h_poly at x; random at x is already in the list).
@@ -1067,7 +1085,7 @@ int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* inst
     std::vector<const Fr*> pp(nq);
     std::vector<Fr> pts(nq);
     for (size_t i = 0; i < nq; i++) pp[i] = ev[i].poly, pts[i] = ev[i].point;
-    ZK_TRY(h2d(ctx, pk->ptrs, pp.data(), nq * sizeof(Fr*)));
+    ZK_TRY(h2d_staged(ctx, pk, pk->ptrs, pp.data(), nq * sizeof(Fr*)));
     ZK_TRY(upload_small(pts, 0));
     ZK_TRY(zk_poly_eval(ctx, (const Fr* const*)pk->ptrs, pk->small, pk->small + nq, nq, (uint32_t)n));
     std::vector<Fr> res(nq);
@@ -1080,6 +1098,7 @@ int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* inst
       if (q.poly == p && q.rot == rot) return q.eval;
     return Fr::zero();
   };
+  tick("evals");
   // 8. multiopen queries in upstream order
   struct PQ {
     const Fr* poly;
@@ -1152,11 +1171,8 @@ int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* inst
       memcpy(r.l, c.data(), 32);
       return to_mont(r);
     };
-    auto get_eval = [&](const Fr* poly, const std::array<uint64_t, 4>& pt) -> Fr {
-      for (size_t i = 0; i < queries.size(); i++)
-        if (queries[i].poly == poly && qcanon[i] == pt) return queries[i].eval;
-      return Fr::zero();
-    };
+    std::map<std::pair<const Fr*, std::array<uint64_t, 4>>, Fr> eval_map;
+    for (size_t i = 0; i < queries.size(); i++) eval_map[{queries[i].poly, qcanon[i]}] = queries[i].eval;
     Fr ys = T.squeeze_challenge();
     Fr v = T.squeeze_challenge();
     trace_fr("shplonk_y", ys);
@@ -1166,10 +1182,21 @@ int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* inst
     std::vector<std::vector<std::vector<Fr>>> lows(nr);  // [set][commitment] low-degree equivalent
     for (size_t i = 0; i < nr; i++) {
       for (auto& c : rsets[i].pts) set_pts[i].push_back(point_fr(c));
+      // Lagrange basis of the set's points, once per set: low_ij = sum_t evals_t * basis_t
+      const size_t m = set_pts[i].size();
+      std::vector<std::vector<Fr>> basis(m);
+      for (size_t t = 0; t < m; t++) {
+        std::vector<Fr> unit(m, Fr::zero());
+        unit[t] = Fr::one();
+        basis[t] = lagrange_interpolate(set_pts[i], unit);
+      }
       for (auto* poly : rsets[i].polys) {
-        std::vector<Fr> evals;
-        for (auto& c : rsets[i].pts) evals.push_back(get_eval(poly, c));
-        lows[i].push_back(lagrange_interpolate(set_pts[i], evals));
+        std::vector<Fr> low(m, Fr::zero());
+        for (size_t t = 0; t < m; t++) {
+          const Fr e = eval_map[{poly, rsets[i].pts[t]}];
+          for (size_t d = 0; d < m; d++) low[d] = add(low[d], mul(e, basis[t][d]));
+        }
+        lows[i].push_back(std::move(low));
       }
     }
     // L_i = sum_j y^j P_ij ; N_i = (L_i - sum_j y^j R_ij) / prod (X - p)
@@ -1186,7 +1213,7 @@ int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* inst
         cur = mul(cur, ys);
       }
       maxm = std::max(maxm, set_pts[i].size());
-      ZK_TRY(h2d(ctx, pk->ptrs, rsets[i].polys.data(), m * sizeof(Fr*)));
+      ZK_TRY(h2d_staged(ctx, pk, pk->ptrs, rsets[i].polys.data(), m * sizeof(Fr*)));
       ZK_TRY(upload_small(cf, 0));
       ZK_TRY(upload_small(lowsum, m));
       Fr* Li = pk->sets_L + i * n;
@@ -1194,7 +1221,6 @@ int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* inst
       ZK_TRY(zk_lincomb(ctx, (const Fr* const*)pk->ptrs, pk->small, (uint32_t)m, Li, n, false));
       ZK_TRY(d2d(ctx, Ni, Li, n * 32));
       ZK_TRY(zk_sub_low(ctx, Ni, pk->small + m, (uint32_t)lowsum.size()));
-      ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     for (size_t step = 0; step < maxm; step++) {  // one root per set per launch
       std::vector<Fr*> pp;
@@ -1204,10 +1230,9 @@ int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* inst
           pp.push_back(pk->sets_N + i * n);
           roots.push_back(set_pts[i][step]);
         }
-      ZK_TRY(h2d(ctx, pk->ptrs, pp.data(), pp.size() * sizeof(Fr*)));
+      ZK_TRY(h2d_staged(ctx, pk, pk->ptrs, pp.data(), pp.size() * sizeof(Fr*)));
       ZK_TRY(upload_small(roots, 0));
       ZK_TRY(zk_kate_div(ctx, (Fr* const*)pk->ptrs, pk->small, pp.size(), (uint32_t)n));
-      ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     {
       std::vector<const Fr*> pp(nr);
@@ -1218,10 +1243,9 @@ int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* inst
         cf[i] = cur;
         cur = mul(cur, v);
       }
-      ZK_TRY(h2d(ctx, pk->ptrs, pp.data(), nr * sizeof(Fr*)));
+      ZK_TRY(h2d_staged(ctx, pk, pk->ptrs, pp.data(), nr * sizeof(Fr*)));
       ZK_TRY(upload_small(cf, 0));
       ZK_TRY(zk_lincomb(ctx, (const Fr* const*)pk->ptrs, pk->small, (uint32_t)nr, pk->hx, n, false));
-      ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     std::vector<G1Affine> cm;
     ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G, pk->hx, 1, cm));
@@ -1253,23 +1277,22 @@ int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* inst
     pp[nr] = pk->hx;
     cf[nr] = neg(zt);
     Fr* lx = pk->sets_N;  // reuse
-    ZK_TRY(h2d(ctx, pk->ptrs, pp.data(), (nr + 1) * sizeof(Fr*)));
+    ZK_TRY(h2d_staged(ctx, pk, pk->ptrs, pp.data(), (nr + 1) * sizeof(Fr*)));
     ZK_TRY(upload_small(cf, 0));
     std::vector<Fr> ct1 = {cterm};
     ZK_TRY(upload_small(ct1, nr + 1));
     ZK_TRY(zk_lincomb(ctx, (const Fr* const*)pk->ptrs, pk->small, (uint32_t)(nr + 1), lx, n, false));
     ZK_TRY(zk_sub_low(ctx, lx, pk->small + nr + 1, 1));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     std::vector<Fr*> one_p = {lx};
     std::vector<Fr> one_r = {u};
-    ZK_TRY(h2d(ctx, pk->ptrs, one_p.data(), sizeof(Fr*)));
+    ZK_TRY(h2d_staged(ctx, pk, pk->ptrs, one_p.data(), sizeof(Fr*)));
     ZK_TRY(upload_small(one_r, 0));
     ZK_TRY(zk_kate_div(ctx, (Fr* const*)pk->ptrs, pk->small, 1, (uint32_t)n));
     ZK_TRY(zk_scale(ctx, lx, n, inv(z0)));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G, lx, 1, cm));
     ZK_TRY(write_points(cm, "shplonk_h2"));
   }
+  tick("shplonk");
   *proof_len = T.proof.size();
   if (proof_out) {
     if (proof_cap < T.proof.size()) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: proof buffer too small (%zu < %zu)", proof_cap, T.proof.size());

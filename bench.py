@@ -186,7 +186,7 @@ def main():
                 "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "u32x8 (254-bit Montgomery integers)", "data": "synthetic",
                 "config": {"workload": "create_proof, rsa_sha256_shape %s: %d advice, %d lookups, %d permutation columns, degree %d, "
-                                       "KZG/SHPLONK/Blake2b, witness resident, lookup permutation on host (next row)"
+                                       "KZG/SHPLONK/Blake2b, witness resident"
                                        % (args.shape, desc["num_advice"], len(desc["lookups"]), len(desc["permutation_columns"]), desc["cs_degree"]),
                            "k": K, "extended_k": K + 2, "proof_bytes": len(proofs[-1]), "proofs_per_gpu_per_step": 1,
                            "parallelism": "independent proofs sharded 1/GPU", "setup_s_excluded": round(t_setup, 1)},
