@@ -123,38 +123,68 @@ struct DigitArgs {
   size_t col_stride;     // elements
   uint32_t len;
   uint32_t nb;           // buckets per column = 2^(C-1)
-  uint32_t* hist;        // [ncols][nb]
-  uint32_t* cursor;      // [ncols][nb]   (scatter only)
-  const uint32_t* off0;  // [ncols][nb+1] (scatter only)
+  uint32_t chunk;        // scalars per workgroup
+  uint32_t nblk;         // workgroups per column
+  uint32_t* blk_hist;    // [ncols][nblk][nb]: per-workgroup counts, later per-workgroup start offsets
+  const uint32_t* off0;  // [ncols][nb+1] bucket offsets (scatter only)
   uint32_t* entries;     // [ncols][ecap] (scatter only)
   size_t ecap;
   uint32_t table_n;      // row length of the window table (2^k)
 };
 
+// One workgroup owns `chunk` consecutive scalars of one column. Counting and cursor bumping happen in
+// LDS (ds_add / ds_add_rtn), so global memory sees one coalesced histogram write per workgroup
+// instead of one atomic per digit.
 template <int C, bool SCATTER>
 __global__ __launch_bounds__(MSM_THREADS) void msm_digit_kernel(DigitArgs a) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.len) return;
-  const uint32_t col = blockIdx.y;
-  const uint4* sp = reinterpret_cast<const uint4*>(a.scalars + (size_t)col * a.col_stride + i);
-  uint4 lo = sp[0], hi = sp[1];
-  if ((lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) == 0) return;
-  Fr s;
-  s.l[0] = lo.x; s.l[1] = lo.y; s.l[2] = lo.z; s.l[3] = lo.w;
-  s.l[4] = hi.x; s.l[5] = hi.y; s.l[6] = hi.z; s.l[7] = hi.w;
-  Fr canon = from_mont(s);  // = to_repr() of the original
-  uint32_t* hist = a.hist + (size_t)col * a.nb;
+  extern __shared__ uint32_t lds_cnt[];  // nb counters / cursors
+  const uint32_t col = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
+  uint32_t* gh = a.blk_hist + ((size_t)col * a.nblk + blk) * a.nb;
   if (!SCATTER) {
-    for_each_digit<C>(canon, [&](uint32_t, uint32_t b, uint32_t) { atomicAdd(hist + b, 1u); });
+    for (uint32_t b = t; b < a.nb; b += MSM_THREADS) lds_cnt[b] = 0;
   } else {
-    uint32_t* cur = a.cursor + (size_t)col * a.nb;
     const uint32_t* off = a.off0 + (size_t)col * (a.nb + 1);
-    uint32_t* ent = a.entries + (size_t)col * a.ecap;
-    for_each_digit<C>(canon, [&](uint32_t w, uint32_t b, uint32_t negv) {
-      uint32_t pos = off[b] + atomicAdd(cur + b, 1u);
-      ent[pos] = (w * a.table_n + i) | (negv << 31);
-    });
+    for (uint32_t b = t; b < a.nb; b += MSM_THREADS) lds_cnt[b] = off[b] + gh[b];
   }
+  __syncthreads();
+  const uint32_t lo_i = blk * a.chunk, hi_i = min(lo_i + a.chunk, a.len);
+  uint32_t* ent = a.entries + (size_t)col * a.ecap;
+  for (uint32_t i = lo_i + t; i < hi_i; i += MSM_THREADS) {
+    const uint4* sp = reinterpret_cast<const uint4*>(a.scalars + (size_t)col * a.col_stride + i);
+    uint4 lo = sp[0], hi = sp[1];
+    if ((lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) == 0) continue;
+    Fr s;
+    s.l[0] = lo.x; s.l[1] = lo.y; s.l[2] = lo.z; s.l[3] = lo.w;
+    s.l[4] = hi.x; s.l[5] = hi.y; s.l[6] = hi.z; s.l[7] = hi.w;
+    Fr canon = from_mont(s);  // = to_repr() of the original
+    if (!SCATTER) {
+      for_each_digit<C>(canon, [&](uint32_t, uint32_t b, uint32_t) { atomicAdd(&lds_cnt[b], 1u); });
+    } else {
+      for_each_digit<C>(canon, [&](uint32_t w, uint32_t b, uint32_t negv) {
+        uint32_t pos = atomicAdd(&lds_cnt[b], 1u);
+        ent[pos] = (w * a.table_n + i) | (negv << 31);
+      });
+    }
+  }
+  if (!SCATTER) {
+    __syncthreads();
+    for (uint32_t b = t; b < a.nb; b += MSM_THREADS) gh[b] = lds_cnt[b];
+  }
+}
+
+// Per bucket: turn the per-workgroup counts into per-workgroup start offsets (relative to the
+// bucket's own start) and emit the bucket total.
+__global__ __launch_bounds__(256) void msm_blk_offsets_kernel(uint32_t* blk_hist, uint32_t* cnt, uint32_t nb, uint32_t nblk) {
+  const uint32_t col = blockIdx.y, b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  uint32_t* h = blk_hist + (size_t)col * nblk * nb + b;
+  uint32_t run = 0;
+  for (uint32_t k = 0; k < nblk; k++) {
+    uint32_t v = h[(size_t)k * nb];
+    h[(size_t)k * nb] = run;
+    run += v;
+  }
+  cnt[(size_t)col * nb + b] = run;
 }
 
 // ------------------------------------------------------------------ scan
@@ -289,10 +319,10 @@ __global__ __launch_bounds__(64) void msm_rowcol_kernel(const G1X* dense, uint32
   }
 }
 
-__device__ __forceinline__ G1X x_mul_small(const G1X& p, uint32_t k) {
+__device__ __forceinline__ G1X x_mul_small(const G1X& p, uint32_t k, int nbits) {
   G1X acc = G1X::inf();
 #pragma unroll 1
-  for (int b = 15; b >= 0; b--) {
+  for (int b = nbits - 1; b >= 0; b--) {
     acc = x_dbl(acc);
     if ((k >> b) & 1) acc = x_add(acc, p);
   }
@@ -306,11 +336,11 @@ __global__ __launch_bounds__(512) void msm_fold_kernel(const G1X* rows, const G1
   const uint32_t col = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const uint32_t G = nb >> 6;
   G1X v = G1X::inf();
-  if (t < G) v = x_mul_small(ld_x(rows + (size_t)col * G + t), 64 * t + 1);
+  if (t < G) v = x_mul_small(ld_x(rows + (size_t)col * G + t), 64 * t + 1, 6 + (32 - __clz(G > 1 ? G - 1 : 1)));
   G1X s = wave_sum(v);
   if (lane == 0) part[wv] = s;
   if (wv == 0) {
-    G1X c = x_mul_small(ld_x(cols + (size_t)col * 64 + lane), lane);
+    G1X c = x_mul_small(ld_x(cols + (size_t)col * 64 + lane), lane, 6);
     G1X cs = wave_sum(c);
     if (lane == 0) part[8] = cs;
   }
@@ -342,12 +372,14 @@ uint32_t pick_window_bits(uint32_t k) {
 template <bool SCATTER>
 int launch_digits(amdzk_ctx* ctx, uint32_t c, const DigitArgs& a, dim3 grid) {
   dim3 block(MSM_THREADS);
+  const size_t shmem = (size_t)a.nb * sizeof(uint32_t);
   const char* nm = SCATTER ? "msm_scatter" : "msm_hist";
   switch (c) {
 #define ZK_CASE(CC)                                                \
   case CC: {                                                       \
     auto kfn = msm_digit_kernel<CC, SCATTER>;                      \
-    ZK_LAUNCH(ctx, nm, kfn, grid, block, 0, a);                    \
+    if (shmem > 65536) ZK_HIP(ctx, hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
+    ZK_LAUNCH(ctx, nm, kfn, grid, block, shmem, a);                \
   } break;
     ZK_CASE(8) ZK_CASE(9) ZK_CASE(10) ZK_CASE(11) ZK_CASE(12) ZK_CASE(13) ZK_CASE(14) ZK_CASE(15) ZK_CASE(16)
 #undef ZK_CASE
@@ -540,50 +572,56 @@ int zk_msm_dev_xyzz(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const Fr* d
   uint32_t T1 = 4;
   while (T1 < 64 && e_total / T1 > 262144) T1 <<= 1;
   if (const char* e = getenv("AMDZK_MSM_T1")) T1 = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : T1;
-  const uint32_t T2 = 8;
+  const uint32_t T2 = 8, T3 = 8;
   const size_t cap1 = ecap / T1 + nb + 1;
   const size_t cap2 = cap1 / T2 + nb + 1;
+  const size_t cap3 = cap2 / T3 + nb + 1;
+  // counting-sort geometry: one workgroup per `chunk` scalars, at most 64 workgroups per column
+  uint32_t chunk = 2048;
+  while ((len + chunk - 1) / chunk > 64) chunk <<= 1;
+  const uint32_t nblk = len ? (uint32_t)((len + chunk - 1) / chunk) : 1;
 
-  // workspace layout (slot 1): hist | cursor | off0 | off1 | off2 | entries | list1 | list2 | dense | rows | cols | out
+  // workspace layout (slot 1)
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
-  const size_t o_hist = take(ncols * nb * 4), o_cur = take(ncols * nb * 4);
-  const size_t o_off0 = take(ncols * (nb + 1) * 4), o_off1 = take(ncols * (nb + 1) * 4), o_off2 = take(ncols * (nb + 1) * 4);
+  const size_t o_bh = take(ncols * (size_t)nblk * nb * 4), o_cnt = take(ncols * nb * 4);
+  const size_t o_off0 = take(ncols * (nb + 1) * 4), o_off1 = take(ncols * (nb + 1) * 4), o_off2 = take(ncols * (nb + 1) * 4),
+               o_off3 = take(ncols * (nb + 1) * 4);
   const size_t o_ent = take(ncols * ecap * 4);
-  const size_t o_l1 = take(ncols * cap1 * sizeof(G1X)), o_l2 = take(ncols * cap2 * sizeof(G1X));
+  const size_t o_l1 = take(ncols * cap1 * sizeof(G1X)), o_l2 = take(ncols * cap2 * sizeof(G1X)), o_l3 = take(ncols * cap3 * sizeof(G1X));
   const size_t o_dense = take(ncols * nb * sizeof(G1X));
   const size_t G = nb >> 6;
   const size_t o_rows = take(ncols * G * sizeof(G1X)), o_cols = take(ncols * 64 * sizeof(G1X));
   const size_t o_out = take(ncols * sizeof(G1X));
   char* ws = nullptr;
   ZK_TRY(zk_ws_reserve(ctx, 1, o, (void**)&ws));
-  uint32_t* hist = (uint32_t*)(ws + o_hist);
-  uint32_t* cursor = (uint32_t*)(ws + o_cur);
-  uint32_t *off0 = (uint32_t*)(ws + o_off0), *off1 = (uint32_t*)(ws + o_off1), *off2 = (uint32_t*)(ws + o_off2);
+  uint32_t* blk_hist = (uint32_t*)(ws + o_bh);
+  uint32_t* cnt = (uint32_t*)(ws + o_cnt);
+  uint32_t *off0 = (uint32_t*)(ws + o_off0), *off1 = (uint32_t*)(ws + o_off1), *off2 = (uint32_t*)(ws + o_off2), *off3 = (uint32_t*)(ws + o_off3);
   uint32_t* entries = (uint32_t*)(ws + o_ent);
-  G1X *l1 = (G1X*)(ws + o_l1), *l2 = (G1X*)(ws + o_l2), *dense = (G1X*)(ws + o_dense);
+  G1X *l1 = (G1X*)(ws + o_l1), *l2 = (G1X*)(ws + o_l2), *l3 = (G1X*)(ws + o_l3), *dense = (G1X*)(ws + o_dense);
   G1X *rows = (G1X*)(ws + o_rows), *cols = (G1X*)(ws + o_cols), *outp = (G1X*)(ws + o_out);
-
-  // hist and cursor are adjacent: one memset
-  ZK_HIP(ctx, hipMemsetAsync(hist, 0, (o_off0 - o_hist), ctx->stream));
 
   DigitArgs da;
   da.scalars = d_scalars;
   da.col_stride = col_stride;
   da.len = (uint32_t)len;
   da.nb = nb;
-  da.hist = hist;
-  da.cursor = cursor;
+  da.chunk = chunk;
+  da.nblk = nblk;
+  da.blk_hist = blk_hist;
   da.off0 = off0;
   da.entries = entries;
   da.ecap = ecap;
   da.table_n = (uint32_t)srs->n;
-  dim3 dgrid((unsigned)((len + MSM_THREADS - 1) / MSM_THREADS), (unsigned)ncols);
-  if (len > 0) ZK_TRY(launch_digits<false>(ctx, c, da, dgrid));
-  ZK_LAUNCH(ctx, "msm_scan", msm_scan_kernel, dim3((unsigned)ncols), dim3(1024), 0, hist, off0, nb, 1u, 1);
-  if (len > 0) ZK_TRY(launch_digits<true>(ctx, c, da, dgrid));
+  dim3 dgrid(nblk, (unsigned)ncols);
+  ZK_TRY(launch_digits<false>(ctx, c, da, dgrid));
+  ZK_LAUNCH(ctx, "msm_blk_offsets", msm_blk_offsets_kernel, dim3((nb + 255) / 256, (unsigned)ncols), dim3(256), 0, blk_hist, cnt, nb, nblk);
+  ZK_LAUNCH(ctx, "msm_scan", msm_scan_kernel, dim3((unsigned)ncols), dim3(1024), 0, cnt, off0, nb, 1u, 1);
+  ZK_TRY(launch_digits<true>(ctx, c, da, dgrid));
   ZK_LAUNCH(ctx, "msm_scan", msm_scan_kernel, dim3((unsigned)ncols), dim3(1024), 0, off0, off1, nb, T1, 0);
   ZK_LAUNCH(ctx, "msm_scan", msm_scan_kernel, dim3((unsigned)ncols), dim3(1024), 0, off1, off2, nb, T2, 0);
+  ZK_LAUNCH(ctx, "msm_scan", msm_scan_kernel, dim3((unsigned)ncols), dim3(1024), 0, off2, off3, nb, T3, 0);
 
   AccArgs a1;
   a1.off_in = off0; a1.off_out = off1; a1.nb = nb; a1.T = T1;
@@ -596,8 +634,13 @@ int zk_msm_dev_xyzz(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const Fr* d
   a2.in_list = l1; a2.in_cap = cap1; a2.out_list = l2; a2.out_cap = cap2;
   ZK_LAUNCH(ctx, "msm_accum_l2", msm_accum_kernel<false>, dim3((unsigned)((cap2 + MSM_THREADS - 1) / MSM_THREADS), (unsigned)ncols),
             dim3(MSM_THREADS), 0, a2);
+  AccArgs a3 = a2;
+  a3.off_in = off2; a3.off_out = off3; a3.T = T3;
+  a3.in_list = l2; a3.in_cap = cap2; a3.out_list = l3; a3.out_cap = cap3;
+  ZK_LAUNCH(ctx, "msm_accum_l3", msm_accum_kernel<false>, dim3((unsigned)((cap3 + MSM_THREADS - 1) / MSM_THREADS), (unsigned)ncols),
+            dim3(MSM_THREADS), 0, a3);
   ZK_LAUNCH(ctx, "msm_accum_final", msm_accum_final_kernel, dim3((nb + MSM_THREADS - 1) / MSM_THREADS, (unsigned)ncols),
-            dim3(MSM_THREADS), 0, off2, nb, l2, cap2, dense);
+            dim3(MSM_THREADS), 0, off3, nb, l3, cap3, dense);
   ZK_LAUNCH(ctx, "msm_rowcol", msm_rowcol_kernel, dim3((unsigned)(G + 64), (unsigned)ncols), dim3(64), 0, dense, nb, rows, cols);
   const unsigned fold_threads = G > 64 ? (unsigned)G : 64u;
   ZK_LAUNCH(ctx, "msm_fold", msm_fold_kernel, dim3((unsigned)ncols), dim3(fold_threads), 0, rows, cols, nb, outp);
