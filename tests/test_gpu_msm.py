@@ -126,3 +126,23 @@ def test_srs_setup_on_device_matches_oracle(ctx, pkg, oracle):
     b = zu.jac_to_affine_host(oracle, params.commit(od.lagrange_to_coeff(p)))
     assert np.array_equal(a, b) and np.array_equal(a, oracle.best_multiexp(p, gl))
     params.free()
+
+
+def test_msm_k22_full_size_tau_identity(ctx, pkg, oracle):
+    """BASELINE config 5 size. With bases g_i = s^i G (device-built SRS), MSM(c, g) must equal
+    eval_polynomial(c, s) * G — a size-independent identity checked at n = 2^22 against the oracle's
+    Horner evaluation and one oracle scalar multiplication."""
+    k = 22
+    n = 1 << k
+    s = zu.fr_from_int(7 ** 20)
+    params = pkg.kzg.ParamsKZG.setup(ctx, k, s)
+    for seed, kind in ((42, "uniform"), (43, "skewed")):
+        c = zu.random_fr(n, seed=seed)
+        if kind == "skewed":
+            sel = zu.splitmix64(seed + 9, n) % np.uint64(4)
+            c[sel < 2] = 0
+        got = zu.jac_to_affine_host(oracle, params.commit(c))
+        e = oracle.eval_polynomial(c, s)
+        want = oracle.g1_mul_many(oracle.generator(), e.reshape(1, 4))[0]
+        assert np.array_equal(got, want), kind
+    params.free()
