@@ -154,10 +154,22 @@ inline void g1_compress(const bn254::G1Affine& p, uint8_t out[32]) {
 }
 
 // ------------------------------------------------------------------------------ transcript
-class Blake2bWrite {
+// halo2_proofs::transcript::TranscriptWrite, as far as the prover uses it.
+class TranscriptWrite {
+ public:
+  virtual ~TranscriptWrite() {}
+  virtual Fr squeeze_challenge() = 0;
+  virtual bool common_point(const bn254::G1Affine& p) = 0;
+  virtual void common_scalar(const Fr& s) = 0;
+  virtual bool write_point(const bn254::G1Affine& p) = 0;
+  virtual void write_scalar(const Fr& s) = 0;
+  std::vector<uint8_t> proof;
+};
+
+class Blake2bWrite : public TranscriptWrite {
  public:
   Blake2bWrite() : st_("Halo2-Transcript") {}
-  Fr squeeze_challenge() {
+  Fr squeeze_challenge() override {
     uint8_t z = 0;  // BLAKE2B_PREFIX_CHALLENGE
     st_.update(&z, 1);
     uint8_t d[64];
@@ -166,7 +178,7 @@ class Blake2bWrite {
     memcpy(l, d, 64);
     return fr_from_u512(l);
   }
-  bool common_point(const bn254::G1Affine& p) {
+  bool common_point(const bn254::G1Affine& p) override {
     if (p.is_inf()) return false;  // "cannot write points at infinity to the transcript"
     uint8_t one = 1, b[32];
     st_.update(&one, 1);
@@ -176,29 +188,137 @@ class Blake2bWrite {
     st_.update(b, 32);
     return true;
   }
-  void common_scalar(const Fr& s) {
+  void common_scalar(const Fr& s) override {
     uint8_t two = 2, b[32];
     st_.update(&two, 1);
     fr_to_repr(s, b);
     st_.update(b, 32);
   }
-  bool write_point(const bn254::G1Affine& p) {
+  bool write_point(const bn254::G1Affine& p) override {
     if (!common_point(p)) return false;
     uint8_t b[32];
     g1_compress(p, b);
     proof.insert(proof.end(), b, b + 32);
     return true;
   }
-  void write_scalar(const Fr& s) {
+  void write_scalar(const Fr& s) override {
     common_scalar(s);
     uint8_t b[32];
     fr_to_repr(s, b);
     proof.insert(proof.end(), b, b + 32);
   }
-  std::vector<uint8_t> proof;
 
  private:
   Blake2b st_;
+};
+
+// ------------------------------------------------------------------------------ Keccak-256 (EVM)
+// Keccak-f[1600] sponge, rate 136, pad10*1 with domain byte 0x01 (the EVM's keccak256, NOT SHA3-256).
+inline void keccak256(const uint8_t* data, size_t len, uint8_t out[32]) {
+  static const uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+                                  0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+                                  0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+                                  0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+                                  0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+                                  0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+  static const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+  uint64_t st[25];
+  memset(st, 0, sizeof(st));
+  auto permute = [&]() {
+    for (int round = 0; round < 24; round++) {
+      uint64_t c[5], d[5], b[25];
+      for (int x = 0; x < 5; x++) c[x] = st[x] ^ st[x + 5] ^ st[x + 10] ^ st[x + 15] ^ st[x + 20];
+      for (int x = 0; x < 5; x++) d[x] = c[(x + 4) % 5] ^ ((c[(x + 1) % 5] << 1) | (c[(x + 1) % 5] >> 63));
+      for (int i = 0; i < 25; i++) st[i] ^= d[i % 5];
+      for (int x = 0; x < 5; x++)
+        for (int y = 0; y < 5; y++) {
+          int i = x + 5 * y, r = ROT[i];
+          uint64_t v = st[i];
+          b[y + 5 * ((2 * x + 3 * y) % 5)] = r ? ((v << r) | (v >> (64 - r))) : v;
+        }
+      for (int y = 0; y < 5; y++)
+        for (int x = 0; x < 5; x++) st[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+      st[0] ^= RC[round];
+    }
+  };
+  const size_t rate = 136;
+  size_t off = 0;
+  while (len - off >= rate) {
+    for (size_t i = 0; i < rate / 8; i++) {
+      uint64_t w;
+      memcpy(&w, data + off + 8 * i, 8);
+      st[i] ^= w;
+    }
+    permute();
+    off += rate;
+  }
+  uint8_t last[136];
+  memset(last, 0, rate);
+  memcpy(last, data + off, len - off);
+  last[len - off] ^= 0x01;
+  last[rate - 1] ^= 0x80;
+  for (size_t i = 0; i < rate / 8; i++) {
+    uint64_t w;
+    memcpy(&w, last + 8 * i, 8);
+    st[i] ^= w;
+  }
+  permute();
+  memcpy(out, st, 32);
+}
+
+// 256-bit big-endian integer mod r -> Montgomery Fr (ChallengeEvm::new / u256_to_fe)
+inline Fr fr_from_be32(const uint8_t be[32]) {
+  uint64_t l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 32; i++) l[i / 8] |= (uint64_t)be[31 - i] << (8 * (i % 8));
+  return fr_from_u512(l);
+}
+
+// halo2-solidity-verifier's Keccak256Transcript + ChallengeEvm, the transcript the reference's
+// solidity_verifier_contract/contract.sol re-derives (:89-112 squeeze_challenge / _cont, :77-87 points):
+// a running byte buffer of 32-byte big-endian words; challenge = keccak256(buffer) mod r; the hash
+// becomes the new buffer, and a squeeze with nothing absorbed since appends the byte 0x01.
+class Keccak256Write : public TranscriptWrite {
+ public:
+  Fr squeeze_challenge() override {
+    std::vector<uint8_t> data(buf_);
+    if (data.size() == 32) data.push_back(1);
+    uint8_t h[32];
+    keccak256(data.data(), data.size(), h);
+    buf_.assign(h, h + 32);
+    return fr_from_be32(h);
+  }
+  bool common_point(const bn254::G1Affine& p) override {
+    if (p.is_inf()) return false;
+    uint8_t b[32];
+    fq_to_repr(p.x, b);
+    for (int i = 31; i >= 0; i--) buf_.push_back(b[i]);
+    fq_to_repr(p.y, b);
+    for (int i = 31; i >= 0; i--) buf_.push_back(b[i]);
+    return true;
+  }
+  void common_scalar(const Fr& s) override {
+    uint8_t b[32];
+    fr_to_repr(s, b);
+    for (int i = 31; i >= 0; i--) buf_.push_back(b[i]);
+  }
+  bool write_point(const bn254::G1Affine& p) override {
+    if (!common_point(p)) return false;
+    uint8_t b[32];
+    fq_to_repr(p.x, b);
+    for (int i = 31; i >= 0; i--) proof.push_back(b[i]);
+    fq_to_repr(p.y, b);
+    for (int i = 31; i >= 0; i--) proof.push_back(b[i]);
+    return true;
+  }
+  void write_scalar(const Fr& s) override {
+    common_scalar(s);
+    uint8_t b[32];
+    fr_to_repr(s, b);
+    for (int i = 31; i >= 0; i--) proof.push_back(b[i]);
+  }
+
+ private:
+  std::vector<uint8_t> buf_;
 };
 
 // ------------------------------------------------------------------------------ ChaCha20Rng

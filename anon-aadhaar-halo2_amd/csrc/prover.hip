@@ -841,8 +841,19 @@ int amdzk_pk_commitments(const amdzk_pk* pk, uint64_t* fixed_out /* F x 8 */, ui
   return AMDZK_OK;
 }
 
+int amdzk_create_proof_ex(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances, const size_t* instance_lens, const void* d_advice,
+                          size_t advice_stride, uint64_t rng_seed, int transcript_kind, uint8_t* proof_out, size_t proof_cap,
+                          size_t* proof_len);
+
 int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances, const size_t* instance_lens, const void* d_advice,
                        size_t advice_stride, uint64_t rng_seed, uint8_t* proof_out, size_t proof_cap, size_t* proof_len) {
+  return amdzk_create_proof_ex(ctx, pk, instances, instance_lens, d_advice, advice_stride, rng_seed, AMDZK_TRANSCRIPT_BLAKE2B, proof_out,
+                               proof_cap, proof_len);
+}
+
+int amdzk_create_proof_ex(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances, const size_t* instance_lens, const void* d_advice,
+                          size_t advice_stride, uint64_t rng_seed, int transcript_kind, uint8_t* proof_out, size_t proof_cap,
+                          size_t* proof_len) {
   if (!ctx) return AMDZK_E_INVALID;
   if (!pk || !proof_len || (pk->A && !d_advice)) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: null argument");
   const size_t n = pk->n, ext = pk->ext;
@@ -850,7 +861,11 @@ int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* inst
   const size_t usable = n - (bf + 1);
   if (advice_stride < n) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: advice stride < n");
   ChaCha20Rng rng(rng_seed);
-  Blake2bWrite T;
+  zkhost::Blake2bWrite t_blake;
+  zkhost::Keccak256Write t_keccak;
+  if (transcript_kind != AMDZK_TRANSCRIPT_BLAKE2B && transcript_kind != AMDZK_TRANSCRIPT_KECCAK256_EVM)
+    ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: unknown transcript kind %d", transcript_kind);
+  zkhost::TranscriptWrite& T = transcript_kind == AMDZK_TRANSCRIPT_BLAKE2B ? (zkhost::TranscriptWrite&)t_blake : (zkhost::TranscriptWrite&)t_keccak;
   const bool ttrace = getenv("AMDZK_TRACE_TIME") != nullptr;
   auto tnow = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double tlast = tnow();

@@ -64,6 +64,7 @@ def lib():
         "amdzk_pk_free": (None, [vp, vp]),
         "amdzk_pk_commitments": (i32, [vp, vp, vp]),
         "amdzk_create_proof": (i32, [vp, vp, C.POINTER(vp), C.POINTER(sz), vp, sz, C.c_uint64, vp, sz, C.POINTER(sz)]),
+        "amdzk_create_proof_ex": (i32, [vp, vp, C.POINTER(vp), C.POINTER(sz), vp, sz, C.c_uint64, i32, vp, sz, C.POINTER(sz)]),
         "amdzk_timer_start": (i32, [vp]),
         "amdzk_timer_stop": (i32, [vp, C.POINTER(C.c_float)]),
         "amdzk_prof_enable": (i32, [vp, i32]),

@@ -353,7 +353,10 @@ class ProvingKey:
             self.h = None
 
 
-def create_proof(ctx, pk, instances, d_advice, seed, advice_stride=None):
+TRANSCRIPT_BLAKE2B, TRANSCRIPT_KECCAK256_EVM = 0, 1
+
+
+def create_proof(ctx, pk, instances, d_advice, seed, advice_stride=None, transcript=TRANSCRIPT_BLAKE2B):
     """plonk::create_proof(params, pk, &[circuit], &[instances], ChaCha20Rng::seed_from_u64(seed), transcript).
     instances: list of (len, 4) uint64 arrays; d_advice: DeviceBuffer (or anything with .ptr) holding
     num_advice columns of n rows. Returns the proof bytes."""
@@ -364,6 +367,6 @@ def create_proof(ctx, pk, instances, d_advice, seed, advice_stride=None):
     need = C.c_size_t(0)
     cap = 1 << 20
     buf = (C.c_uint8 * cap)()
-    ctx._chk(ctx.L.amdzk_create_proof(ctx.h, pk.h, ptrs, lens, d_advice.ptr if d_advice is not None else None, advice_stride or n,
-                                      C.c_uint64(seed), buf, cap, C.byref(need)))
+    ctx._chk(ctx.L.amdzk_create_proof_ex(ctx.h, pk.h, ptrs, lens, d_advice.ptr if d_advice is not None else None, advice_stride or n,
+                                         C.c_uint64(seed), transcript, buf, cap, C.byref(need)))
     return bytes(buf[: need.value])

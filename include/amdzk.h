@@ -184,6 +184,16 @@ int amdzk_pk_commitments(const amdzk_pk* pk, uint64_t* fixed_out, uint64_t* perm
 int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances,
                        const size_t* instance_lens, const void* d_advice, size_t advice_stride,
                        uint64_t rng_seed, uint8_t* proof_out, size_t proof_cap, size_t* proof_len);
+/* Same with a choice of TranscriptWrite: Blake2bWrite/Challenge255 (32-byte compressed points,
+ * little-endian scalars) or halo2-solidity-verifier's Keccak256Transcript/ChallengeEvm — the wire
+ * format /root/reference/solidity_verifier_contract/contract.sol reads (64-byte uncompressed points,
+ * 32-byte big-endian scalars, contract.sol:77-112). */
+#define AMDZK_TRANSCRIPT_BLAKE2B 0
+#define AMDZK_TRANSCRIPT_KECCAK256_EVM 1
+int amdzk_create_proof_ex(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances,
+                          const size_t* instance_lens, const void* d_advice, size_t advice_stride,
+                          uint64_t rng_seed, int transcript_kind, uint8_t* proof_out,
+                          size_t proof_cap, size_t* proof_len);
 
 /* ---- timing / profiling hooks used by bench.py (HIP events on this ctx's stream) ------------ */
 int amdzk_timer_start(amdzk_ctx* ctx);

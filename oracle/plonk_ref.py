@@ -150,6 +150,97 @@ class Blake2bRead(Blake2bWrite):
         return s
 
 
+def keccak256(data):
+    """Keccak-256 as the EVM computes it (pad byte 0x01, not SHA3's 0x06); pure Python."""
+    RC = [0x0000000000000001, 0x0000000000008082, 0x800000000000808A, 0x8000000080008000, 0x000000000000808B, 0x0000000080000001,
+          0x8000000080008081, 0x8000000000008009, 0x000000000000008A, 0x0000000000000088, 0x0000000080008009, 0x000000008000000A,
+          0x000000008000808B, 0x800000000000008B, 0x8000000000008089, 0x8000000000008003, 0x8000000000008002, 0x8000000000000080,
+          0x000000000000800A, 0x800000008000000A, 0x8000000080008081, 0x8000000000008080, 0x0000000080000001, 0x8000000080008008]
+    M = (1 << 64) - 1
+    rol = lambda v, n: ((v << n) | (v >> (64 - n))) & M if n else v
+    st = [[0] * 5 for _ in range(5)]  # st[x][y]
+
+    def f():
+        for rc in RC:
+            c = [st[x][0] ^ st[x][1] ^ st[x][2] ^ st[x][3] ^ st[x][4] for x in range(5)]
+            d = [c[(x - 1) % 5] ^ rol(c[(x + 1) % 5], 1) for x in range(5)]
+            for x in range(5):
+                for y in range(5):
+                    st[x][y] ^= d[x]
+            x, y, cur = 1, 0, st[1][0]
+            for t in range(24):  # rho + pi
+                x, y = y, (2 * x + 3 * y) % 5
+                cur, st[x][y] = st[x][y], rol(cur, ((t + 1) * (t + 2) // 2) % 64)
+            for y in range(5):  # chi
+                row = [st[x][y] for x in range(5)]
+                for x in range(5):
+                    st[x][y] = row[x] ^ ((~row[(x + 1) % 5]) & M & row[(x + 2) % 5])
+            st[0][0] ^= rc
+
+    rate = 136
+    data = bytearray(data)
+    data.append(0x01)
+    while len(data) % rate:
+        data.append(0)
+    data[-1] |= 0x80
+    for off in range(0, len(data), rate):
+        for i in range(rate // 8):
+            st[i % 5][i // 5] ^= int.from_bytes(data[off + 8 * i:off + 8 * i + 8], "little")
+        f()
+    return b"".join(st[i % 5][i // 5].to_bytes(8, "little") for i in range(4))
+
+
+class Keccak256Write:
+    """halo2-solidity-verifier Keccak256Transcript + ChallengeEvm [UP], i.e. what
+    /root/reference/solidity_verifier_contract/contract.sol:77-112 re-derives."""
+
+    def __init__(self):
+        self.buf = bytearray()
+        self.proof = bytearray()
+
+    def squeeze_challenge(self):
+        data = bytes(self.buf) + (b"\x01" if len(self.buf) == 32 else b"")
+        h = keccak256(data)
+        self.buf = bytearray(h)
+        return int.from_bytes(h, "big") % R
+
+    def common_point(self, p):
+        assert p is not None
+        self.buf += p[0].to_bytes(32, "big") + p[1].to_bytes(32, "big")
+
+    def common_scalar(self, s):
+        self.buf += (s % R).to_bytes(32, "big")
+
+    def write_point(self, p):
+        self.common_point(p)
+        self.proof += p[0].to_bytes(32, "big") + p[1].to_bytes(32, "big")
+
+    def write_scalar(self, s):
+        self.common_scalar(s)
+        self.proof += (s % R).to_bytes(32, "big")
+
+
+class Keccak256Read(Keccak256Write):
+    def __init__(self, proof):
+        super().__init__()
+        self.data, self.pos = bytes(proof), 0
+
+    def read_point(self):
+        x = int.from_bytes(self.data[self.pos:self.pos + 32], "big")
+        y = int.from_bytes(self.data[self.pos + 32:self.pos + 64], "big")
+        self.pos += 64
+        assert x < Q and y < Q and (y * y - x * x * x - 3) % Q == 0, "point not on curve"
+        self.common_point((x, y))
+        return (x, y)
+
+    def read_scalar(self):
+        s = int.from_bytes(self.data[self.pos:self.pos + 32], "big")
+        self.pos += 32
+        assert s < R
+        self.common_scalar(s)
+        return s
+
+
 # ------------------------------------------------------------------------------------ helpers
 def batch_invert(v):
     return [pow(x, -1, R) if x else 0 for x in v]
@@ -326,7 +417,7 @@ def poly_eval_fn(polys_by_kind, d):
     return get_at
 
 
-def create_proof(pk, instances, advice_values, seed, trace=None):
+def create_proof(pk, instances, advice_values, seed, trace=None, transcript="blake2b"):
     """plonk::prover::create_proof for one circuit instance, KZG + SHPLONK + Blake2b, phase 0 only.
     instances[c] = list of public inputs of instance column c; advice_values[c] = n ints (rows past
     the usable range are overwritten by blinding). Returns the proof bytes."""
@@ -334,7 +425,7 @@ def create_proof(pk, instances, advice_values, seed, trace=None):
     bf = desc["blinding_factors"]
     usable = n - (bf + 1)
     rng = ChaCha20Rng(seed)
-    T = Blake2bWrite()
+    T = Blake2bWrite() if transcript == "blake2b" else Keccak256Write()
     tr = (lambda *a: trace.append(a)) if trace is not None else (lambda *a: None)
     T.common_scalar(pk.transcript_repr)
     # instances
@@ -656,12 +747,12 @@ def lagrange_basis_at(d, n, rows, x):
     return out
 
 
-def verify_proof(pk, instances, proof):
+def verify_proof(pk, instances, proof, transcript="blake2b"):
     """Checks: transcript re-derivation, the vanishing identity at x, and the SHPLONK opening equation
     (in G1, with the known tau standing in for the pairing). Raises AssertionError on failure."""
     desc, d, n, tau = pk.desc, pk.domain, pk.n, pk.tau
     bf = desc["blinding_factors"]
-    T = Blake2bRead(proof)
+    T = Blake2bRead(proof) if transcript == "blake2b" else Keccak256Read(proof)
     T.common_scalar(pk.transcript_repr)
     for col in instances:
         for v in col:

@@ -104,3 +104,25 @@ def test_rsa_sha256_shape_k15_verifies(ctx, pkg, plonk, oracle):
     proof = plonk.create_proof(ctx, pk, inst, d_adv, seed=2024)
     assert PR.verify_proof(vk_from_device(pk, c), c.instances, proof)
     d_adv.free(); pk.free(); params.free()
+
+
+def test_evm_proof_accepted_by_reference_solidity_verifier(ctx, pkg, plonk, oracle):
+    """Config 1/3 of BASELINE.json in the form the reference can check: the SquareCircuit
+    (/root/reference/src/signal.rs) proved on the MI355X with the Keccak256/EVM transcript equals the
+    oracle prover's bytes and is accepted by the restated contract.sol (oracle/contract_sol.py)."""
+    import contract_sol as CS
+
+    for k in (4, 8):
+        c = circuits.square_circuit(plonk, k, signal=5)
+        params, pk, d_adv, inst = setup(ctx, pkg, plonk, oracle, c, transcript_repr_int=0xABCDEF)
+        got = plonk.create_proof(ctx, pk, inst, d_adv, seed=21, transcript=plonk.TRANSCRIPT_KECCAK256_EVM)
+        assert len(got) == 0x0460  # contract.sol:221
+        opk = PR.keygen(c.desc, c.fixed, c.assembly.mapping, TAU, transcript_repr=0xABCDEF)
+        assert got == PR.create_proof(opk, c.instances, c.advice, seed=21, transcript="evm")
+        f, p = pk.commitments()
+        vk = CS.vk_words(0xABCDEF, 0, k, [zu.point_to_ints(x) for x in f], [zu.point_to_ints(x) for x in p])
+        assert CS.verify_proof(vk, got, [], TAU)
+        bad = bytearray(got)
+        bad[-1] ^= 1
+        assert not CS.verify_proof(vk, bytes(bad), [], TAU)
+        d_adv.free(); pk.free(); params.free()

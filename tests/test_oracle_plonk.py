@@ -99,3 +99,26 @@ def test_rsa_shape_budget(plonk):
     assert d["cs_degree"] == 4 and d["blinding_factors"] == 6
     full = plonk.ConstraintSystem
     assert full is not None
+
+
+def test_reference_solidity_verifier_accepts_square_circuit_proof(plonk):
+    """The reference's own verifier — solidity_verifier_contract/contract.sol, restated statement by
+    statement in oracle/contract_sol.py (pairing replaced by the known-trapdoor check) — accepts the
+    SquareCircuit proof in the EVM wire format (Keccak256 transcript, 0x460 bytes, contract.sol:221)
+    and rejects a tampered proof and an unsatisfied witness."""
+    import contract_sol as CS
+
+    for k in (4, 6):
+        c = circuits.square_circuit(plonk, k, signal=7)
+        pk = PR.keygen(c.desc, c.fixed, c.assembly.mapping, TAU, transcript_repr=0xABCDEF)
+        proof = PR.create_proof(pk, c.instances, c.advice, seed=11, transcript="evm")
+        assert len(proof) == 0x0460
+        assert PR.verify_proof(pk, c.instances, proof, transcript="evm")
+        vk = CS.vk_words(pk.transcript_repr, 0, k, pk.fixed_commitments, pk.permutation_commitments)
+        assert CS.verify_proof(vk, proof, [], TAU)
+        bad = bytearray(proof)
+        bad[0x0284 - 0x84 + 31] ^= 1  # a_0(x), calldata 0x0284
+        assert not CS.verify_proof(vk, bytes(bad), [], TAU)
+        adv = [list(col) for col in c.advice]
+        adv[1][0] += 1
+        assert not CS.verify_proof(vk, PR.create_proof(pk, c.instances, adv, seed=11, transcript="evm"), [], TAU)

@@ -48,12 +48,50 @@ __global__ void fqsqr_add_kernel(Fq* out, int iters) {
   for (int i = 0; i < iters; i++) { x = add(x, y); y = sub(y, x); x = add(x, x); y = sub(x, y); }
   out[blockIdx.x * blockDim.x + threadIdx.x] = add(x, y);
 }
-__global__ void madd_kernel(G1X* out, int iters) {
+// per-lane distinct data (a uniform input gets scalarised by the compiler and measures the SALU)
+__global__ void madd_kernel(G1X* out, const G1Affine* pts, int iters) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  G1Affine g = pts[tid & 1023];
+  G1X acc = x_dbl_affine(pts[(tid + 7) & 1023]);
+  for (int i = 0; i < iters; i++) acc = x_add_affine(acc, g);
+  out[tid] = acc;
+}
+// same work with the field product kept out of line (one copy of the 3 KB multiply in the I-cache)
+__device__ __noinline__ Fq mul_nl(const Fq& a, const Fq& b) { return mul(a, b); }
+__device__ __forceinline__ G1X x_add_affine_nl(const G1X& a, const G1Affine& q) {
+  Fq u2 = mul_nl(q.x, a.zz);
+  Fq s2 = mul_nl(q.y, a.zzz);
+  Fq p = sub(u2, a.x);
+  Fq r = sub(s2, a.y);
+  Fq pp = mul_nl(p, p);
+  Fq ppp = mul_nl(p, pp);
+  Fq qq = mul_nl(a.x, pp);
+  G1X o;
+  o.x = sub(sub(mul_nl(r, r), ppp), dbl(qq));
+  o.y = sub(mul_nl(r, sub(qq, o.x)), mul_nl(a.y, ppp));
+  o.zz = mul_nl(a.zz, pp);
+  o.zzz = mul_nl(a.zzz, ppp);
+  return o;
+}
+__global__ void madd_nl_kernel(G1X* out, const G1Affine* pts, int iters) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  G1Affine g = pts[tid & 1023];
+  G1X acc = x_dbl_affine(pts[(tid + 7) & 1023]);
+  for (int i = 0; i < iters; i++) acc = x_add_affine_nl(acc, g);
+  out[tid] = acc;
+}
+__global__ void fqmul_var_kernel(Fq* out, const G1Affine* pts, int iters) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  Fq x = pts[tid & 1023].x, y = pts[(tid + 3) & 1023].y;
+  for (int i = 0; i < iters; i++) { x = mul(x, y); y = mul(y, x); }
+  out[tid] = add(x, y);
+}
+__global__ void gen_points_kernel(G1Affine* pts) {  // pts[i] = (i+2) G, 1024 points
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
   G1Affine g; g.x = Fq::one(); g.y = add(Fq::one(), Fq::one());
   G1X acc = x_dbl_affine(g);
-  acc.x.l[0] ^= 0;  // keep generic
-  for (int i = 0; i < iters; i++) acc = x_add_affine(acc, g);
-  out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+  for (int k = 0; k < i; k++) acc = x_add_affine(acc, g);
+  pts[i] = x_to_affine(acc);
 }
 
 template <class K>
@@ -103,11 +141,21 @@ int main() {
     double n = (double)blocks * 256 * iters * 4;
     printf("{\"bench\": \"fq_addsub\", \"waves_per_simd\": %d, \"ms\": %.3f, \"Gop_per_s\": %.2f}\n", wps, ms, n / ms * 1e-6);
   }
-  for (int wps = 1; wps <= 4; wps *= 2) {
+  G1Affine* pts; CK(hipMalloc(&pts, 1024 * sizeof(G1Affine)));
+  gen_points_kernel<<<4, 256>>>(pts); CK(hipDeviceSynchronize());
+  for (int wps = 1; wps <= 8; wps *= 2) {
     int blocks = cus * wps, iters = 200;
-    float ms = time_it([&]() { madd_kernel<<<blocks, 256>>>((G1X*)buf, iters); }, 3);
+    float ms = time_it([&]() { fqmul_var_kernel<<<blocks, 256>>>((Fq*)buf, pts, iters); }, 3);
+    double n = (double)blocks * 256 * iters * 2;
+    printf("{\"bench\": \"fq_mul_varying_data\", \"waves_per_simd\": %d, \"ms\": %.3f, \"Gmul_per_s\": %.2f}\n", wps, ms, n / ms * 1e-6);
+  }
+  for (int wps = 1; wps <= 4; wps *= 2) {
+    int blocks = cus * wps, iters = 100;
+    float ms = time_it([&]() { madd_kernel<<<blocks, 256>>>((G1X*)buf, pts, iters); }, 3);
     double n = (double)blocks * 256 * iters;
     printf("{\"bench\": \"g1_mixed_add_xyzz\", \"waves_per_simd\": %d, \"ms\": %.3f, \"Madd_per_s\": %.1f, \"us_per_dependent_add\": %.3f}\n", wps, ms, n / ms * 1e-3, ms * 1e3 / iters);
+    ms = time_it([&]() { madd_nl_kernel<<<blocks, 256>>>((G1X*)buf, pts, iters); }, 3);
+    printf("{\"bench\": \"g1_mixed_add_xyzz_noinline_mul\", \"waves_per_simd\": %d, \"ms\": %.3f, \"Madd_per_s\": %.1f, \"us_per_dependent_add\": %.3f}\n", wps, ms, n / ms * 1e-3, ms * 1e3 / iters);
   }
   return 0;
 }
