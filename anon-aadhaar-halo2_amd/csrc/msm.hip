@@ -189,18 +189,24 @@ __global__ __launch_bounds__(256) void msm_blk_offsets_kernel(uint32_t* blk_hist
 
 // ------------------------------------------------------------------ scan
 // off_out[b] = exclusive prefix sum over b of v[b]; off_out[nb] = total.
-//   src_is_hist: v[b] = src[b]                      (src has nb entries per column)
-//   else       : v[b] = ceil((src[b+1]-src[b]) / T)  (src has nb+1 entries per column)
+//   mode 1: v[b] = src[b]                       (src has nb entries per column)
+//   mode 0: v[b] = ceil((src[b+1]-src[b]) / T)   (src has nb+1 entries per column)
+//   mode 2: v[b] = number of T-aligned chunks of the whole list that intersect [src[b], src[b+1])
 __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* src, uint32_t* off_out,
                                                          uint32_t nb, uint32_t T, int src_is_hist) {
   __shared__ uint32_t part[1024];
   const uint32_t col = blockIdx.x, t = threadIdx.x;
-  const uint32_t* s = src + (size_t)col * (src_is_hist ? nb : nb + 1);
+  const uint32_t* s = src + (size_t)col * (src_is_hist == 1 ? nb : nb + 1);
   uint32_t* o = off_out + (size_t)col * (nb + 1);
   const uint32_t per = (nb + 1023) / 1024;
   const uint32_t b0 = t * per, b1 = min(b0 + per, nb);
+  auto val = [&](uint32_t b) -> uint32_t {
+    if (src_is_hist == 1) return s[b];
+    if (src_is_hist == 0) return (s[b + 1] - s[b] + T - 1) / T;
+    return s[b + 1] > s[b] ? (s[b + 1] - 1) / T - s[b] / T + 1 : 0u;
+  };
   uint32_t sum = 0;
-  for (uint32_t b = b0; b < b1; b++) sum += src_is_hist ? s[b] : (s[b + 1] - s[b] + T - 1) / T;
+  for (uint32_t b = b0; b < b1; b++) sum += val(b);
   part[t] = sum;
   __syncthreads();
   for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* src, uin
   uint32_t run = part[t] - sum;
   for (uint32_t b = b0; b < b1; b++) {
     o[b] = run;
-    run += src_is_hist ? s[b] : (s[b + 1] - s[b] + T - 1) / T;
+    run += val(b);
   }
   if (t == 1023) o[nb] = part[1023];
 }
@@ -232,35 +238,51 @@ struct AccArgs {
   size_t out_cap;
 };
 
+// Balanced accumulation level (FIRST: table points by id; otherwise partial sums of the previous
+// level): thread t owns entries [t*T, (t+1)*T) of the column's sorted list, whatever
+// buckets they belong to, and emits one partial sum per bucket segment it crosses (slot
+// off_out[b] + (t - off_in[b]/T)). Every lane of a wavefront performs the same number of additions,
+// so skewed witness columns (thousands of tiny buckets next to a few huge ones) no longer leave most
+// lanes idle behind the longest task.
 template <bool FIRST>
-__global__ __launch_bounds__(MSM_THREADS) void msm_accum_kernel(AccArgs a) {
+__global__ __launch_bounds__(MSM_THREADS) void msm_accum_seg_kernel(AccArgs a) {
   const uint32_t col = blockIdx.y;
-  const uint32_t task = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t* off_in = a.off_in + (size_t)col * (a.nb + 1);
   const uint32_t* off_out = a.off_out + (size_t)col * (a.nb + 1);
-  if (task >= off_out[a.nb]) return;
-  uint32_t lo = 0, hi = a.nb;  // largest b with off_out[b] <= task
+  const uint32_t total = off_in[a.nb];
+  const uint32_t start = t * a.T;
+  if (start >= total) return;
+  const uint32_t end = min(start + a.T, total);
+  uint32_t lo = 0, hi = a.nb;  // largest b with off_in[b] <= start: the non-empty bucket holding `start`
   while (hi - lo > 1) {
     uint32_t mid = (lo + hi) >> 1;
-    if (off_out[mid] <= task) lo = mid; else hi = mid;
+    if (off_in[mid] <= start) lo = mid; else hi = mid;
   }
-  const uint32_t sub = task - off_out[lo];
-  const uint32_t start = off_in[lo] + sub * a.T;
-  const uint32_t end = min(start + a.T, off_in[lo + 1]);
+  uint32_t b = lo, b_end = off_in[b + 1];
+  const uint32_t* ent = FIRST ? a.entries + (size_t)col * a.ecap : nullptr;
+  const G1X* in = FIRST ? nullptr : a.in_list + (size_t)col * a.in_cap;
+  G1X* out = a.out_list + (size_t)col * a.out_cap;
   G1X acc = G1X::inf();
-  if (FIRST) {
-    const uint32_t* ent = a.entries + (size_t)col * a.ecap;
-    for (uint32_t e = start; e < end; e++) {
+  for (uint32_t e = start; e < end; e++) {
+    if (e >= b_end) {  // crossed into the next non-empty bucket: flush
+      st_x(out + off_out[b] + (t - off_in[b] / a.T), acc);
+      acc = G1X::inf();
+      do {
+        b++;
+        b_end = off_in[b + 1];
+      } while (e >= b_end);
+    }
+    if (FIRST) {
       uint32_t id = ent[e];
       G1Affine p = ld_aff(a.table + (id & 0x7fffffffu));
-      if (id >> 31) p.y = neg(p.y);  // table points are never the identity unless the base is
+      if (id >> 31) p.y = neg(p.y);
       acc = x_add_affine(acc, p);
+    } else {
+      acc = x_add(acc, ld_x(in + e));
     }
-  } else {
-    const G1X* in = a.in_list + (size_t)col * a.in_cap;
-    for (uint32_t e = start; e < end; e++) acc = x_add(acc, ld_x(in + e));
   }
-  st_x(a.out_list + (size_t)col * a.out_cap + task, acc);
+  st_x(out + off_out[b] + (t - off_in[b] / a.T), acc);
 }
 
 // Final level: one thread per bucket folds whatever is left and writes the dense bucket array.
@@ -567,15 +589,20 @@ int zk_msm_dev_xyzz(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const Fr* d
   const size_t ecap = align_up(len * W ? len * W : 1, 4);
   if ((uint64_t)W * srs->n >= (1ull << 31)) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "msm: table too large for 31-bit ids");
 
-  // task sizes
+  // task sizes: level 1 adds T1 table points per thread, levels 2.. fold TL partial sums per thread;
+  // all levels use the balanced segmented kernel. Measured (profiles/r01g_msm_task_sweep.txt): with
+  // several proofs in flight throughput is flat in T1 (the chip is work-bound), and every extra
+  // folding level costs a latency-bound launch, so: big tasks, two folding levels.
   const size_t e_total = ecap * ncols;
   uint32_t T1 = 4;
-  while (T1 < 64 && e_total / T1 > 262144) T1 <<= 1;
+  while (T1 < 32 && e_total / T1 > 262144) T1 <<= 1;
   if (const char* e = getenv("AMDZK_MSM_T1")) T1 = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : T1;
-  const uint32_t T2 = 8, T3 = 8;
-  const size_t cap1 = ecap / T1 + nb + 1;
-  const size_t cap2 = cap1 / T2 + nb + 1;
-  const size_t cap3 = cap2 / T3 + nb + 1;
+  const uint32_t TL = 8;
+  constexpr int NLEV = 3;  // level 1 + two folding levels, then the per-bucket final
+  size_t cap[NLEV + 1];
+  cap[0] = ecap;
+  cap[1] = ecap / T1 + nb + 1;
+  for (int l = 2; l <= NLEV; l++) cap[l] = cap[l - 1] / TL + nb + 1;
   // counting-sort geometry: one workgroup per `chunk` scalars, at most 64 workgroups per column
   uint32_t chunk = 2048;
   while ((len + chunk - 1) / chunk > 64) chunk <<= 1;
@@ -585,10 +612,11 @@ int zk_msm_dev_xyzz(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const Fr* d
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
   const size_t o_bh = take(ncols * (size_t)nblk * nb * 4), o_cnt = take(ncols * nb * 4);
-  const size_t o_off0 = take(ncols * (nb + 1) * 4), o_off1 = take(ncols * (nb + 1) * 4), o_off2 = take(ncols * (nb + 1) * 4),
-               o_off3 = take(ncols * (nb + 1) * 4);
+  size_t o_off[NLEV + 1], o_list[NLEV + 1];
+  for (int l = 0; l <= NLEV; l++) o_off[l] = take(ncols * (nb + 1) * 4);
   const size_t o_ent = take(ncols * ecap * 4);
-  const size_t o_l1 = take(ncols * cap1 * sizeof(G1X)), o_l2 = take(ncols * cap2 * sizeof(G1X)), o_l3 = take(ncols * cap3 * sizeof(G1X));
+  o_list[0] = 0;
+  for (int l = 1; l <= NLEV; l++) o_list[l] = take(ncols * cap[l] * sizeof(G1X));
   const size_t o_dense = take(ncols * nb * sizeof(G1X));
   const size_t G = nb >> 6;
   const size_t o_rows = take(ncols * G * sizeof(G1X)), o_cols = take(ncols * 64 * sizeof(G1X));
@@ -597,9 +625,11 @@ int zk_msm_dev_xyzz(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const Fr* d
   ZK_TRY(zk_ws_reserve(ctx, 1, o, (void**)&ws));
   uint32_t* blk_hist = (uint32_t*)(ws + o_bh);
   uint32_t* cnt = (uint32_t*)(ws + o_cnt);
-  uint32_t *off0 = (uint32_t*)(ws + o_off0), *off1 = (uint32_t*)(ws + o_off1), *off2 = (uint32_t*)(ws + o_off2), *off3 = (uint32_t*)(ws + o_off3);
+  uint32_t* off[NLEV + 1];
+  G1X* list[NLEV + 1];
+  for (int l = 0; l <= NLEV; l++) off[l] = (uint32_t*)(ws + o_off[l]), list[l] = (G1X*)(ws + o_list[l]);
   uint32_t* entries = (uint32_t*)(ws + o_ent);
-  G1X *l1 = (G1X*)(ws + o_l1), *l2 = (G1X*)(ws + o_l2), *l3 = (G1X*)(ws + o_l3), *dense = (G1X*)(ws + o_dense);
+  G1X* dense = (G1X*)(ws + o_dense);
   G1X *rows = (G1X*)(ws + o_rows), *cols = (G1X*)(ws + o_cols), *outp = (G1X*)(ws + o_out);
 
   DigitArgs da;
@@ -610,37 +640,39 @@ int zk_msm_dev_xyzz(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const Fr* d
   da.chunk = chunk;
   da.nblk = nblk;
   da.blk_hist = blk_hist;
-  da.off0 = off0;
+  da.off0 = off[0];
   da.entries = entries;
   da.ecap = ecap;
   da.table_n = (uint32_t)srs->n;
   dim3 dgrid(nblk, (unsigned)ncols);
   ZK_TRY(launch_digits<false>(ctx, c, da, dgrid));
   ZK_LAUNCH(ctx, "msm_blk_offsets", msm_blk_offsets_kernel, dim3((nb + 255) / 256, (unsigned)ncols), dim3(256), 0, blk_hist, cnt, nb, nblk);
-  ZK_LAUNCH(ctx, "msm_scan", msm_scan_kernel, dim3((unsigned)ncols), dim3(1024), 0, cnt, off0, nb, 1u, 1);
+  ZK_LAUNCH(ctx, "msm_scan", msm_scan_kernel, dim3((unsigned)ncols), dim3(1024), 0, cnt, off[0], nb, 1u, 1);
   ZK_TRY(launch_digits<true>(ctx, c, da, dgrid));
-  ZK_LAUNCH(ctx, "msm_scan", msm_scan_kernel, dim3((unsigned)ncols), dim3(1024), 0, off0, off1, nb, T1, 0);
-  ZK_LAUNCH(ctx, "msm_scan", msm_scan_kernel, dim3((unsigned)ncols), dim3(1024), 0, off1, off2, nb, T2, 0);
-  ZK_LAUNCH(ctx, "msm_scan", msm_scan_kernel, dim3((unsigned)ncols), dim3(1024), 0, off2, off3, nb, T3, 0);
-
-  AccArgs a1;
-  a1.off_in = off0; a1.off_out = off1; a1.nb = nb; a1.T = T1;
-  a1.entries = entries; a1.ecap = ecap; a1.table = srs->table[basis];
-  a1.in_list = nullptr; a1.in_cap = 0; a1.out_list = l1; a1.out_cap = cap1;
-  ZK_LAUNCH(ctx, "msm_accum_l1", msm_accum_kernel<true>, dim3((unsigned)((cap1 + MSM_THREADS - 1) / MSM_THREADS), (unsigned)ncols),
-            dim3(MSM_THREADS), 0, a1);
-  AccArgs a2 = a1;
-  a2.off_in = off1; a2.off_out = off2; a2.T = T2; a2.entries = nullptr; a2.table = nullptr;
-  a2.in_list = l1; a2.in_cap = cap1; a2.out_list = l2; a2.out_cap = cap2;
-  ZK_LAUNCH(ctx, "msm_accum_l2", msm_accum_kernel<false>, dim3((unsigned)((cap2 + MSM_THREADS - 1) / MSM_THREADS), (unsigned)ncols),
-            dim3(MSM_THREADS), 0, a2);
-  AccArgs a3 = a2;
-  a3.off_in = off2; a3.off_out = off3; a3.T = T3;
-  a3.in_list = l2; a3.in_cap = cap2; a3.out_list = l3; a3.out_cap = cap3;
-  ZK_LAUNCH(ctx, "msm_accum_l3", msm_accum_kernel<false>, dim3((unsigned)((cap3 + MSM_THREADS - 1) / MSM_THREADS), (unsigned)ncols),
-            dim3(MSM_THREADS), 0, a3);
+  for (int l = 1; l <= NLEV; l++) {
+    const uint32_t T = l == 1 ? T1 : TL;
+    ZK_LAUNCH(ctx, "msm_scan", msm_scan_kernel, dim3((unsigned)ncols), dim3(1024), 0, off[l - 1], off[l], nb, T, 2);
+    AccArgs a;
+    a.off_in = off[l - 1];
+    a.off_out = off[l];
+    a.nb = nb;
+    a.T = T;
+    a.entries = entries;
+    a.ecap = ecap;
+    a.table = srs->table[basis];
+    a.in_list = list[l - 1];
+    a.in_cap = cap[l - 1];
+    a.out_list = list[l];
+    a.out_cap = cap[l];
+    const size_t threads = (cap[l - 1] + T - 1) / T;
+    dim3 grid((unsigned)((threads + MSM_THREADS - 1) / MSM_THREADS), (unsigned)ncols);
+    if (l == 1)
+      ZK_LAUNCH(ctx, "msm_accum_l1", msm_accum_seg_kernel<true>, grid, dim3(MSM_THREADS), 0, a);
+    else
+      ZK_LAUNCH(ctx, "msm_accum_fold", msm_accum_seg_kernel<false>, grid, dim3(MSM_THREADS), 0, a);
+  }
   ZK_LAUNCH(ctx, "msm_accum_final", msm_accum_final_kernel, dim3((nb + MSM_THREADS - 1) / MSM_THREADS, (unsigned)ncols),
-            dim3(MSM_THREADS), 0, off3, nb, l3, cap3, dense);
+            dim3(MSM_THREADS), 0, off[NLEV], nb, list[NLEV], cap[NLEV], dense);
   ZK_LAUNCH(ctx, "msm_rowcol", msm_rowcol_kernel, dim3((unsigned)(G + 64), (unsigned)ncols), dim3(64), 0, dense, nb, rows, cols);
   const unsigned fold_threads = G > 64 ? (unsigned)G : 64u;
   ZK_LAUNCH(ctx, "msm_fold", msm_fold_kernel, dim3((unsigned)ncols), dim3(fold_threads), 0, rows, cols, nb, outp);

@@ -238,8 +238,9 @@ uint32_t env_u32(const char* name, uint32_t dflt) {
 }
 
 Plan make_plan(uint32_t log_n, uint32_t tile_log) {
-  // Keep at least 4 elements (128 contiguous bytes) per global run: s <= tile_log - 2.
-  uint32_t smax = tile_log - 2;
+  // Keep at least 4 elements (128 contiguous bytes) per global run: s <= tile_log - 2
+  // (AMDZK_NTT_SMAX_SLACK=1 allows 2-element runs when that saves a whole step).
+  uint32_t smax = tile_log - 2 + env_u32("AMDZK_NTT_SMAX_SLACK", 1);
   Plan p;
   if (log_n <= tile_log) {  // whole column in one tile
     p.npass = 1;
@@ -274,7 +275,7 @@ int zk_ntt_ex(amdzk_ctx* ctx, const Fr* d_in, size_t in_stride, Fr* d_out, size_
   if (ncols > 65535) ZK_FAIL(ctx, AMDZK_E_INVALID, "ntt: more than 65535 columns in one call");
   Fr* tw = nullptr;
   ZK_TRY(get_twiddles(ctx, log_n, omega, &tw));
-  const uint32_t tile_log = env_u32("AMDZK_NTT_TILE_LOG", 11);
+  const uint32_t tile_log = env_u32("AMDZK_NTT_TILE_LOG", 10);
   Plan plan = make_plan(log_n, tile_log);
 
   Fr* ws = nullptr;

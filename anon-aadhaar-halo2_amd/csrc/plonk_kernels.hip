@@ -38,6 +38,14 @@ __device__ __forceinline__ void st_fr(Fr* p, const Fr& v) {
 }
 
 // ------------------------------------------------------------------------------ interpreter
+// Two latency measures, both value-neutral: (1) columns that almost every constraint touches at
+// rotation 0 (l_0, l_last, l_active and the coset point X) are loaded once per row into registers
+// ("hot" slots, ExprArgs::hot); (2) the column operand of the NEXT instruction is fetched while the
+// current one executes, so a global load is in flight behind every field multiplication.
+__device__ __forceinline__ bool op_reads_col(uint32_t op) {
+  return op == OP_PUSH_COL || op == OP_MUL_COL || op == OP_ADD_COL || op == OP_SUB_COL;
+}
+
 __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_kernel(ExprArgs a) {
   extern __shared__ uint4 lds_raw[];
   Fr* stack = reinterpret_cast<Fr*>(lds_raw);  // [depth][EXPR_THREADS]
@@ -47,30 +55,48 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_kernel(ExprArgs a) {
   Fr tos = Fr::zero();
   Fr h = Fr::zero();
   const Fr yv = ld_fr(a.consts + a.y_const);
+  Fr hot[EXPR_HOT];
+#pragma unroll
+  for (int i = 0; i < EXPR_HOT; i++) hot[i] = a.hot[i] != EXPR_NO_SLOT ? ld_fr(a.cols[a.hot[i]] + row) : Fr::zero();
   uint32_t sp = 0;  // elements on the stack, including tos
+  // operand prefetch state
+  Fr pre = Fr::zero();
+  uint32_t w = a.prog_len ? a.prog[0] : 0;
+  auto fetch = [&](uint32_t word) -> Fr {
+    const uint32_t arg = word & 0xffffffu;
+    const Fr* col = a.cols[arg >> 8];
+    const size_t idx = (row + (size_t)(int64_t)a.rot_off[arg & 0xff]) & a.mask;
+    return ld_fr(col + idx);
+  };
+  if (a.prog_len && op_reads_col(w >> 24)) pre = fetch(w);
   for (uint32_t pc = 0; pc < a.prog_len; pc++) {
-    const uint32_t w = a.prog[pc];
     const uint32_t op = w >> 24, arg = w & 0xffffffu;
+    const Fr v = pre;  // operand of this instruction (if it has one), fetched one instruction ago
+    const uint32_t wn = pc + 1 < a.prog_len ? a.prog[pc + 1] : 0;
+    if (op_reads_col(wn >> 24)) pre = fetch(wn);
     switch (op) {
       case OP_PUSH_COL:
+        if (sp > 0) stack[(sp - 1) * EXPR_THREADS + tid] = tos;
+        tos = v;
+        sp++;
+        break;
       case OP_MUL_COL:
+        tos = mul(tos, v);
+        break;
       case OP_ADD_COL:
-      case OP_SUB_COL: {
-        const Fr* col = a.cols[arg >> 8];
-        const size_t idx = (row + (size_t)(int64_t)a.rot_off[arg & 0xff]) & a.mask;
-        Fr v = ld_fr(col + idx);
-        if (op == OP_PUSH_COL) {
-          if (sp > 0) stack[(sp - 1) * EXPR_THREADS + tid] = tos;
-          tos = v;
-          sp++;
-        } else if (op == OP_MUL_COL) {
-          tos = mul(tos, v);
-        } else if (op == OP_ADD_COL) {
-          tos = add(tos, v);
-        } else {
-          tos = sub(tos, v);
-        }
-      } break;
+        tos = add(tos, v);
+        break;
+      case OP_SUB_COL:
+        tos = sub(tos, v);
+        break;
+      case OP_PUSH_HOT:
+        if (sp > 0) stack[(sp - 1) * EXPR_THREADS + tid] = tos;
+        tos = arg == 0 ? hot[0] : arg == 1 ? hot[1] : arg == 2 ? hot[2] : hot[3];
+        sp++;
+        break;
+      case OP_MUL_HOT:
+        tos = mul(tos, arg == 0 ? hot[0] : arg == 1 ? hot[1] : arg == 2 ? hot[2] : hot[3]);
+        break;
       case OP_PUSH_CONST:
         if (sp > 0) stack[(sp - 1) * EXPR_THREADS + tid] = tos;
         tos = ld_fr(a.consts + arg);
@@ -113,6 +139,7 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_kernel(ExprArgs a) {
       default:
         break;
     }
+    w = wn;
   }
   if (a.h_out) st_fr(a.h_out + row, h);
 }

@@ -21,7 +21,12 @@ enum ExprOp : uint32_t {
   OP_ACC = 12,    // h = h*y + pop()
   OP_STORE = 13,  // outs[arg][row] = pop()
   OP_SQR = 14,
+  OP_PUSH_HOT = 15,  // push hot[arg]
+  OP_MUL_HOT = 16,   // tos *= hot[arg]
 };
+
+constexpr int EXPR_HOT = 4;
+constexpr uint32_t EXPR_NO_SLOT = 0xffffffffu;
 
 struct ExprArgs {
   const uint32_t* prog;
@@ -34,6 +39,7 @@ struct ExprArgs {
   size_t mask;                   // rows - 1
   size_t nrows;
   uint32_t y_const;              // index of y in consts (OP_ACC)
+  uint32_t hot[EXPR_HOT];        // column slots held in registers for the whole row (rotation 0), or EXPR_NO_SLOT
 };
 
 int zk_expr_eval(amdzk_ctx* ctx, const ExprArgs& a, uint32_t depth, const char* name);

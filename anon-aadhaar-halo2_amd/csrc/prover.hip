@@ -64,6 +64,7 @@ Fr fr_delta() {  // Fr::DELTA = 7^(2^28)  (contract.sol:440)
 struct Program {
   std::vector<uint32_t> words;
   uint32_t depth = 0, cur = 0;
+  bool uses_hot = false;
   uint32_t* d_words = nullptr;
   void op(uint32_t o, uint32_t arg = 0) { words.push_back((o << 24) | (arg & 0xffffffu)); }
   void push() {
@@ -237,48 +238,136 @@ int commit_cols(amdzk_ctx* ctx, amdzk_pk* pk, int basis, const Fr* d_cols, size_
   return AMDZK_OK;
 }
 
-// translate a host-format postfix expression into device ops; Lagrange and extended programs share
-// slot numbers for fixed/advice/instance columns.
+// Translate a host-format postfix expression into device ops. The postfix words are first rebuilt
+// into a tree so that a binary operation with a leaf operand (a column or a constant) becomes ONE
+// fused instruction on the top of stack (MUL_COL / ADD_COL / SUB_COL / MUL_CONST / ADD_CONST) instead
+// of push + pop through the LDS stack. Field addition and multiplication are exact and commutative,
+// so the value is the one upstream's Expression::evaluate produces. Lagrange and extended programs
+// share slot numbers for fixed/advice/instance columns.
+struct ENode {
+  uint32_t op, payload;
+  int l, r;
+};
+
+int emit_tree(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, const std::vector<ENode>& t, int i) {
+  const ENode& n = t[i];
+  auto is_col = [&](int j) { return t[j].op == XOP_FIXED || t[j].op == XOP_ADVICE || t[j].op == XOP_INSTANCE; };
+  auto col_arg = [&](int j) -> uint32_t {
+    const ENode& c = t[j];
+    uint32_t col = c.payload >> 8;
+    int32_t rot = (int32_t)(c.payload & 0xff) - 128;
+    uint32_t slot = c.op == XOP_FIXED ? pk->sl_fixed(col) : c.op == XOP_ADVICE ? pk->sl_adv(col) : pk->sl_inst(col);
+    return (slot << 8) | pk->rots.index(rot);
+  };
+  switch (n.op) {
+    case XOP_CONST:
+      pr.op(OP_PUSH_CONST, n.payload);
+      pr.push();
+      return AMDZK_OK;
+    case XOP_FIXED:
+    case XOP_ADVICE:
+    case XOP_INSTANCE:
+      pr.op(OP_PUSH_COL, col_arg(i));
+      pr.push();
+      return AMDZK_OK;
+    case XOP_NEG:
+      ZK_TRY(emit_tree(ctx, pk, pr, t, n.l));
+      pr.op(OP_NEG);
+      return AMDZK_OK;
+    case XOP_SCALE:
+      ZK_TRY(emit_tree(ctx, pk, pr, t, n.l));
+      pr.op(OP_MUL_CONST, n.payload);
+      return AMDZK_OK;
+    case XOP_ADD: {
+      int a = n.l, b = n.r;
+      if (t[b].op == XOP_NEG && is_col(t[b].l)) {  // a + (-col) -> a - col
+        ZK_TRY(emit_tree(ctx, pk, pr, t, a));
+        pr.op(OP_SUB_COL, col_arg(t[b].l));
+        return AMDZK_OK;
+      }
+      if (!is_col(b) && t[b].op != XOP_CONST && (is_col(a) || t[a].op == XOP_CONST)) std::swap(a, b);
+      if (is_col(b)) {
+        ZK_TRY(emit_tree(ctx, pk, pr, t, a));
+        pr.op(OP_ADD_COL, col_arg(b));
+        return AMDZK_OK;
+      }
+      if (t[b].op == XOP_CONST) {
+        ZK_TRY(emit_tree(ctx, pk, pr, t, a));
+        pr.op(OP_ADD_CONST, t[b].payload);
+        return AMDZK_OK;
+      }
+      ZK_TRY(emit_tree(ctx, pk, pr, t, a));
+      ZK_TRY(emit_tree(ctx, pk, pr, t, b));
+      pr.op(OP_ADD);
+      pr.pop();
+      return AMDZK_OK;
+    }
+    case XOP_MUL: {
+      int a = n.l, b = n.r;
+      if (!is_col(b) && t[b].op != XOP_CONST && (is_col(a) || t[a].op == XOP_CONST)) std::swap(a, b);
+      if (is_col(b)) {
+        ZK_TRY(emit_tree(ctx, pk, pr, t, a));
+        pr.op(OP_MUL_COL, col_arg(b));
+        return AMDZK_OK;
+      }
+      if (t[b].op == XOP_CONST) {
+        ZK_TRY(emit_tree(ctx, pk, pr, t, a));
+        pr.op(OP_MUL_CONST, t[b].payload);
+        return AMDZK_OK;
+      }
+      ZK_TRY(emit_tree(ctx, pk, pr, t, a));
+      ZK_TRY(emit_tree(ctx, pk, pr, t, b));
+      pr.op(OP_MUL);
+      pr.pop();
+      return AMDZK_OK;
+    }
+    default:
+      ZK_FAIL(ctx, AMDZK_E_INVALID, "circuit: bad expression node %u", n.op);
+  }
+}
+
 int emit_expr(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, const std::vector<uint32_t>& words) {
+  std::vector<ENode> t;
+  std::vector<int> st;
   for (uint32_t w : words) {
     uint32_t op = w >> 24, pl = w & 0xffffffu;
     switch (op) {
       case XOP_CONST:
         if (pl >= pk->c_one) ZK_FAIL(ctx, AMDZK_E_INVALID, "circuit: constant index %u out of range", pl);
-        pr.op(OP_PUSH_CONST, pl);
-        pr.push();
+        t.push_back(ENode{op, pl, -1, -1});
+        st.push_back((int)t.size() - 1);
         break;
       case XOP_FIXED:
       case XOP_ADVICE:
       case XOP_INSTANCE: {
         uint32_t col = pl >> 8;
-        int32_t rot = (int32_t)(pl & 0xff) - 128;
         uint32_t lim = op == XOP_FIXED ? pk->F : op == XOP_ADVICE ? pk->A : pk->I;
         if (col >= lim) ZK_FAIL(ctx, AMDZK_E_INVALID, "circuit: column %u out of range", col);
-        uint32_t slot = op == XOP_FIXED ? pk->sl_fixed(col) : op == XOP_ADVICE ? pk->sl_adv(col) : pk->sl_inst(col);
-        pr.op(OP_PUSH_COL, (slot << 8) | pk->rots.index(rot));
-        pr.push();
+        t.push_back(ENode{op, pl, -1, -1});
+        st.push_back((int)t.size() - 1);
       } break;
       case XOP_NEG:
-        pr.op(OP_NEG);
+      case XOP_SCALE:
+        if (st.empty()) ZK_FAIL(ctx, AMDZK_E_INVALID, "circuit: malformed expression");
+        if (op == XOP_SCALE && pl >= pk->c_one) ZK_FAIL(ctx, AMDZK_E_INVALID, "circuit: constant index %u out of range", pl);
+        t.push_back(ENode{op, pl, st.back(), -1});
+        st.back() = (int)t.size() - 1;
         break;
       case XOP_ADD:
-        pr.op(OP_ADD);
-        pr.pop();
-        break;
-      case XOP_MUL:
-        pr.op(OP_MUL);
-        pr.pop();
-        break;
-      case XOP_SCALE:
-        if (pl >= pk->c_one) ZK_FAIL(ctx, AMDZK_E_INVALID, "circuit: constant index %u out of range", pl);
-        pr.op(OP_MUL_CONST, pl);
-        break;
+      case XOP_MUL: {
+        if (st.size() < 2) ZK_FAIL(ctx, AMDZK_E_INVALID, "circuit: malformed expression");
+        int r = st.back();
+        st.pop_back();
+        int l = st.back();
+        t.push_back(ENode{op, 0, l, r});
+        st.back() = (int)t.size() - 1;
+      } break;
       default:
         ZK_FAIL(ctx, AMDZK_E_INVALID, "circuit: bad expression word %08x", w);
     }
   }
-  return AMDZK_OK;
+  if (st.size() != 1) ZK_FAIL(ctx, AMDZK_E_INVALID, "circuit: malformed expression");
+  return emit_tree(ctx, pk, pr, t, st[0]);
 }
 
 // fold(acc * theta + expr) over a lookup's expressions (first term: 0*theta + e0 = e0)
@@ -311,6 +400,13 @@ int run_program(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, bool extended, Fr* co
   a.nrows = extended ? pk->ext : pk->n;
   a.mask = a.nrows - 1;
   a.y_const = pk->c_y;
+  for (int i = 0; i < EXPR_HOT; i++) a.hot[i] = EXPR_NO_SLOT;
+  if (extended && pr.uses_hot) {
+    a.hot[0] = pk->se_l0();
+    a.hot[1] = pk->se_llast();
+    a.hot[2] = pk->se_lactive();
+    a.hot[3] = pk->se_x();
+  }
   return zk_expr_eval(ctx, a, pr.depth + 1, name);
 }
 
@@ -695,6 +791,7 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
   // (4) the h(X) numerator: gates, permutation, lookups — evaluation.rs evaluate_h order
   {
     Program& pr = pk->prog_h;
+    pr.uses_hot = true;
     auto colkind_slot_ext = colkind_slot_lag;  // fixed/advice/instance share slot numbers in both tables
     for (uint32_t g = 0; g < pk->num_gates; g++) {
       KG_TRY(emit_expr(ctx, pk, pr, pk->exprs[g]));
@@ -705,19 +802,19 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
       // l_0 * (1 - z_0)
       pr.op(OP_PUSH_CONST, pk->c_one); pr.push();
       pr.op(OP_SUB_COL, COL(pk->se_zp(0), r0));
-      pr.op(OP_MUL_COL, COL(pk->se_l0(), r0));
+      pr.op(OP_MUL_HOT, 0);
       pr.op(OP_ACC); pr.pop();
       // l_last * (z_l^2 - z_l)
       pr.op(OP_PUSH_COL, COL(pk->se_zp(ns - 1), r0)); pr.push();
       pr.op(OP_SQR);
       pr.op(OP_SUB_COL, COL(pk->se_zp(ns - 1), r0));
-      pr.op(OP_MUL_COL, COL(pk->se_llast(), r0));
+      pr.op(OP_MUL_HOT, 1);
       pr.op(OP_ACC); pr.pop();
       // l_0 * (z_i - z_{i-1}(omega^last X))
       for (uint32_t s = 1; s < ns; s++) {
         pr.op(OP_PUSH_COL, COL(pk->se_zp(s), r0)); pr.push();
         pr.op(OP_SUB_COL, COL(pk->se_zp(s - 1), rlast));
-        pr.op(OP_MUL_COL, COL(pk->se_l0(), r0));
+        pr.op(OP_MUL_HOT, 0);
         pr.op(OP_ACC); pr.pop();
       }
       // l_active * (z_i(omega X) prod(v + beta sigma + gamma) - z_i(X) prod(v + beta delta^j X + gamma))
@@ -733,14 +830,14 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
         }
         pr.op(OP_PUSH_COL, COL(pk->se_zp(s), r0)); pr.push();
         for (uint32_t j = lo; j < hi; j++) {
-          pr.op(OP_PUSH_COL, COL(pk->se_x(), r0)); pr.push();
+          pr.op(OP_PUSH_HOT, 3); pr.push();
           pr.op(OP_MUL_CONST, pk->c_bdelta + j);
           pr.op(OP_ADD_COL, COL(colkind_slot_ext(pk->perm_cols[j]), r0));
           pr.op(OP_ADD_CONST, pk->c_gamma);
           pr.op(OP_MUL); pr.pop();
         }
         pr.op(OP_SUB); pr.pop();
-        pr.op(OP_MUL_COL, COL(pk->se_lactive(), r0));
+        pr.op(OP_MUL_HOT, 2);
         pr.op(OP_ACC); pr.pop();
       }
     }
@@ -750,13 +847,13 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
       // l_0 * (1 - z)
       pr.op(OP_PUSH_CONST, pk->c_one); pr.push();
       pr.op(OP_SUB_COL, COL(pk->se_zl(l), r0));
-      pr.op(OP_MUL_COL, COL(pk->se_l0(), r0));
+      pr.op(OP_MUL_HOT, 0);
       pr.op(OP_ACC); pr.pop();
       // l_last * (z^2 - z)
       pr.op(OP_PUSH_COL, COL(pk->se_zl(l), r0)); pr.push();
       pr.op(OP_SQR);
       pr.op(OP_SUB_COL, COL(pk->se_zl(l), r0));
-      pr.op(OP_MUL_COL, COL(pk->se_llast(), r0));
+      pr.op(OP_MUL_HOT, 1);
       pr.op(OP_ACC); pr.pop();
       // l_active * (z(wX)(a'+beta)(s'+gamma) - z(X)(ci+beta)(ct+gamma))
       pr.op(OP_PUSH_COL, COL(pk->se_zl(l), r1)); pr.push();
@@ -774,12 +871,12 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
       pr.op(OP_ADD_CONST, pk->c_gamma);
       pr.op(OP_MUL); pr.pop();
       pr.op(OP_SUB); pr.pop();
-      pr.op(OP_MUL_COL, COL(pk->se_lactive(), r0));
+      pr.op(OP_MUL_HOT, 2);
       pr.op(OP_ACC); pr.pop();
       // l_0 * (a' - s')
       pr.op(OP_PUSH_COL, COL(pk->se_la(l), r0)); pr.push();
       pr.op(OP_SUB_COL, COL(pk->se_ls(l), r0));
-      pr.op(OP_MUL_COL, COL(pk->se_l0(), r0));
+      pr.op(OP_MUL_HOT, 0);
       pr.op(OP_ACC); pr.pop();
       // l_active * (a' - s')(a' - a'(w^-1 X))
       pr.op(OP_PUSH_COL, COL(pk->se_la(l), r0)); pr.push();
@@ -787,7 +884,7 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
       pr.op(OP_PUSH_COL, COL(pk->se_la(l), r0)); pr.push();
       pr.op(OP_SUB_COL, COL(pk->se_la(l), rm1));
       pr.op(OP_MUL); pr.pop();
-      pr.op(OP_MUL_COL, COL(pk->se_lactive(), r0));
+      pr.op(OP_MUL_HOT, 2);
       pr.op(OP_ACC); pr.pop();
       e += ni + nt;
     }

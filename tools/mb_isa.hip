@@ -1,0 +1,65 @@
+// Instruction-rate microbenchmark with inline asm (the compiler cannot fold these): lane-ops per CU per clock.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+template <int MODE>
+__global__ void k(uint64_t* out, int iters) {
+  uint32_t x = threadIdx.x * 2654435761u + 12345u, y = x ^ 0x9e3779b9u;
+  uint64_t a0 = x, a1 = y, a2 = x + 7, a3 = y + 9;
+  uint32_t c0 = x, c1 = y, c2 = x + 3, c3 = y + 5;
+  for (int i = 0; i < iters; i++) {
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      if (MODE == 0) {
+        asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_mad_u64_u32 %1, vcc, %4, %5, %1\n\tv_mad_u64_u32 %2, vcc, %4, %5, %2\n\tv_mad_u64_u32 %3, vcc, %4, %5, %3"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(x), "v"(y) : "vcc");
+      } else if (MODE == 1) {
+        asm volatile("v_lshl_add_u64 %0, %0, 0, %1\n\tv_lshl_add_u64 %1, %1, 0, %2\n\tv_lshl_add_u64 %2, %2, 0, %3\n\tv_lshl_add_u64 %3, %3, 0, %0"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+      } else if (MODE == 2) {
+        asm volatile("v_mov_b32 %0, %1\n\tv_mov_b32 %1, %2\n\tv_mov_b32 %2, %3\n\tv_mov_b32 %3, %0" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+      } else if (MODE == 3) {
+        asm volatile("v_add_co_u32 %0, vcc, %0, %1\n\tv_addc_co_u32 %1, vcc, %1, %2, vcc\n\tv_add_co_u32 %2, vcc, %2, %3\n\tv_addc_co_u32 %3, vcc, %3, %0, vcc"
+                     : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : : "vcc");
+      } else if (MODE == 4) {
+        asm volatile("v_mul_lo_u32 %0, %0, %1\n\tv_mul_lo_u32 %1, %1, %2\n\tv_mul_lo_u32 %2, %2, %3\n\tv_mul_lo_u32 %3, %3, %0" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+      } else if (MODE == 5) {  // mad with carry-out consumed by addc (the column-accumulate pattern)
+        asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc\n\tv_mad_u64_u32 %1, vcc, %4, %5, %1\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc"
+                     : "+v"(a0), "+v"(a1), "+v"(c0), "+v"(c1) : "v"(x), "v"(y) : "vcc");
+      }
+    }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ c0 ^ c1 ^ c2 ^ c3;
+}
+
+int main() {
+  hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
+  int cus = p.multiProcessorCount;
+  void* buf; CK(hipMalloc(&buf, (size_t)cus * 8 * 256 * 8));
+  const char* names[6] = {"v_mad_u64_u32", "v_lshl_add_u64", "v_mov_b32", "v_add_co/addc_u32", "v_mul_lo_u32", "mad+addc pair (2 instr)"};
+  for (int mode = 0; mode < 6; mode++)
+    for (int wps = 1; wps <= 8; wps *= 2) {
+      int blocks = cus * wps, iters = 1000;
+      hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+      auto L = [&]() {
+        switch (mode) {
+          case 0: k<0><<<blocks, 256>>>((uint64_t*)buf, iters); break;
+          case 1: k<1><<<blocks, 256>>>((uint64_t*)buf, iters); break;
+          case 2: k<2><<<blocks, 256>>>((uint64_t*)buf, iters); break;
+          case 3: k<3><<<blocks, 256>>>((uint64_t*)buf, iters); break;
+          case 4: k<4><<<blocks, 256>>>((uint64_t*)buf, iters); break;
+          case 5: k<5><<<blocks, 256>>>((uint64_t*)buf, iters); break;
+        }
+      };
+      L(); CK(hipDeviceSynchronize());
+      CK(hipEventRecord(a)); L(); L(); L(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+      float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 3;
+      double instrs = (double)blocks * 256 * iters * 64;  // 16 x 4 instructions per lane
+      double per_cu_clk = instrs / (ms * 1e-3) / cus / (p.clockRate * 1e3);
+      printf("{\"instr\": \"%s\", \"waves_per_simd\": %d, \"ms\": %.3f, \"lane_instr_per_cu_per_clk\": %.1f, \"cycles_per_wave_instr_per_simd\": %.2f}\n",
+             names[mode], wps, ms, per_cu_clk, 256.0 / per_cu_clk);
+    }
+  return 0;
+}
