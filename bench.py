@@ -69,8 +69,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--shape", default="k15", choices=sorted(SHAPES))
-    ap.add_argument("--concurrency", type=int, default=int(os.environ.get("AMDZK_BENCH_CONCURRENCY", "4")),
-                    help="proofs in flight per GPU (each on its own amdzk context / HIP stream / proving-key workspace)")
+    ap.add_argument("--concurrency", type=int, default=int(os.environ.get("AMDZK_BENCH_CONCURRENCY", "0")),
+                    help="proofs in flight per GPU (each on its own amdzk context / HIP stream / proving-key workspace); "
+                         "0 = auto: the largest divisor of --steps in 3..6 (so the timed steps form whole rounds), else 4")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -90,7 +91,10 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    P = max(1, args.concurrency)
+    P = args.concurrency
+    if P <= 0:
+        divs = [d for d in range(3, 7) if args.steps % d == 0]
+        P = max(divs) if divs else min(4, max(1, args.steps))
     ctxs = [pkg.Context(local_rank) for _ in range(P)]
     ctx = ctxs[0]
 
