@@ -16,6 +16,9 @@ int zk_msm_dev_xyzz(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const Fr* d
 int zk_msm_finish(amdzk_ctx* ctx, const G1X* d_res, size_t ncols, uint64_t* out_jac);
 int zk_srs_setup(amdzk_ctx* ctx, uint32_t k, const uint64_t s_mont[4], const uint64_t omega_mont[4], amdzk_srs** out, uint64_t* g_out,
                  uint64_t* g_lagrange_out);
+size_t zk_srs_serialized_size(uint32_t k);
+int zk_srs_write(amdzk_ctx* ctx, const amdzk_srs* s, const uint8_t g2[64], const uint8_t s_g2[64], uint8_t* out, size_t cap);
+int zk_srs_read(amdzk_ctx* ctx, const uint8_t* data, size_t len, amdzk_srs** out, uint8_t g2_out[64], uint8_t s_g2_out[64]);
 extern "C" int amdzk_domain_new(amdzk_ctx* ctx, uint32_t j, uint32_t k, struct amdzk_domain** out);
 extern "C" void amdzk_domain_free(amdzk_ctx* ctx, struct amdzk_domain* d);
 extern "C" int amdzk_domain_constant(const struct amdzk_domain* d, int what, uint64_t out[4]);
@@ -186,6 +189,15 @@ int amdzk_srs_setup(amdzk_ctx* ctx, uint32_t k, const uint64_t s[4], amdzk_srs**
   amdzk_domain_constant(dom, 0, omega);
   amdzk_domain_free(ctx, dom);
   return zk_srs_setup(ctx, k, s, omega, out, g_out, g_lagrange_out);
+}
+size_t amdzk_srs_serialized_size(uint32_t k) { return zk_srs_serialized_size(k); }
+int amdzk_srs_write(amdzk_ctx* ctx, const amdzk_srs* srs, const uint8_t g2[64], const uint8_t s_g2[64], uint8_t* out, size_t cap) {
+  if (!ctx) return AMDZK_E_INVALID;
+  return zk_srs_write(ctx, srs, g2, s_g2, out, cap);
+}
+int amdzk_srs_read(amdzk_ctx* ctx, const uint8_t* data, size_t len, amdzk_srs** out, uint8_t g2_out[64], uint8_t s_g2_out[64]) {
+  if (!ctx) return AMDZK_E_INVALID;
+  return zk_srs_read(ctx, data, len, out, g2_out, s_g2_out);
 }
 void amdzk_srs_free(amdzk_ctx* ctx, amdzk_srs* srs) {
   if (ctx) hipStreamSynchronize(ctx->stream);

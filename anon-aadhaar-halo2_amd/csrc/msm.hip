@@ -524,6 +524,118 @@ __global__ void mul2_kernel(Fr* a, const Fr* w, Fr c, size_t n) {
 
 int zk_batch_invert(amdzk_ctx* ctx, Fr* d_a, Fr* d_scratch, size_t total);
 
+// ---- ParamsKZG::{write, read} [UP]: k as u32 LE, then the n points of g and
+// of g_lagrange in halo2curves' 32-byte compressed form, then g2 and s_g2 (64 bytes each, passed
+// through untouched: the prover never uses G2). Compression / decompression (one Fq square root per
+// point, q = 3 mod 4) run on the device.
+namespace {
+__global__ __launch_bounds__(256) void g1_compress_kernel(const G1Affine* pts, uint8_t* out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  G1Affine p = ld_aff(pts + i);
+  uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (!p.is_inf()) {
+    Fq x = from_mont(p.x), y = from_mont(p.y);
+#pragma unroll
+    for (int j = 0; j < 8; j++) w[j] = x.l[j];
+    w[7] |= (y.l[0] & 1u) << 31;  // byte 31 bit 7 = parity of y
+  }
+  uint4* o = reinterpret_cast<uint4*>(out + 32 * i);
+  o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+__global__ __launch_bounds__(256) void g1_decompress_kernel(const uint8_t* in, G1Affine* out, size_t n, int* err) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint4* q4 = reinterpret_cast<const uint4*>(in + 32 * i);
+  uint4 a = q4[0], b = q4[1];
+  Fq x;
+  x.l[0] = a.x; x.l[1] = a.y; x.l[2] = a.z; x.l[3] = a.w;
+  x.l[4] = b.x; x.l[5] = b.y; x.l[6] = b.z; x.l[7] = b.w;
+  const uint32_t ysign = x.l[7] >> 31;
+  x.l[7] &= 0x7fffffffu;
+  G1Affine p;
+  p.x = Fq::zero();
+  p.y = Fq::zero();
+  bool ok = true;
+  // x must be canonical (< q)
+  {
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      uint64_t t = (uint64_t)x.l[j] - FqP::p(j) - borrow;
+      borrow = (uint32_t)(t >> 63);
+    }
+    ok = borrow == 1;
+  }
+  if (ok && !(x.is_zero() && ysign == 0)) {
+    Fq xm = to_mont(x);
+    Fq three = add(add(Fq::one(), Fq::one()), Fq::one());
+    Fq rhs = add(mul(sqr(xm), xm), three);
+    // (q+1)/4
+    const uint32_t e[8] = {0xb61f3f52u, 0x4f082305u, 0x5a1c72a3u, 0x65e05aa4u, 0xa0605617u, 0x6e14116du, 0xb84c680au, 0x0c19139cu};
+    Fq y = pow_u256(rhs, e);
+    if (sqr(y) != rhs) {
+      ok = false;
+    } else {
+      Fq yc = from_mont(y);
+      if ((yc.l[0] & 1u) != ysign) y = neg(y);
+      p.x = xm;
+      p.y = y;
+    }
+  }
+  if (!ok) atomicExch(err, 1);
+  st_aff(out + i, p);
+}
+}  // namespace
+
+size_t zk_srs_serialized_size(uint32_t k) { return 4 + 2 * ((size_t)32 << k) + 128; }
+
+int zk_srs_write(amdzk_ctx* ctx, const amdzk_srs* s, const uint8_t g2[64], const uint8_t s_g2[64], uint8_t* out, size_t cap) {
+  if (!s || !s->table[0] || !s->table[1] || !out) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_write: both bases must be resident");
+  const size_t need = zk_srs_serialized_size(s->k);
+  if (cap < need) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_write: buffer too small (%zu < %zu)", cap, need);
+  uint8_t* d = nullptr;
+  ZK_TRY(zk_ws_reserve(ctx, 3, 2 * s->n * 32, (void**)&d));
+  dim3 grid((unsigned)((s->n + 255) / 256)), block(256);
+  ZK_LAUNCH(ctx, "g1_compress", g1_compress_kernel, grid, block, 0, s->table[0], d, s->n);
+  ZK_LAUNCH(ctx, "g1_compress", g1_compress_kernel, grid, block, 0, s->table[1], d + s->n * 32, s->n);
+  uint32_t k = s->k;
+  memcpy(out, &k, 4);
+  ZK_HIP(ctx, hipMemcpyAsync(out + 4, d, 2 * s->n * 32, hipMemcpyDeviceToHost, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (g2) memcpy(out + 4 + 2 * s->n * 32, g2, 64); else memset(out + 4 + 2 * s->n * 32, 0, 64);
+  if (s_g2) memcpy(out + 4 + 2 * s->n * 32 + 64, s_g2, 64); else memset(out + 4 + 2 * s->n * 32 + 64, 0, 64);
+  return AMDZK_OK;
+}
+
+static int srs_build(amdzk_ctx* ctx, const void* g, const void* g_lagrange, bool src_on_device, uint32_t k, amdzk_srs** out);
+
+int zk_srs_read(amdzk_ctx* ctx, const uint8_t* data, size_t len, amdzk_srs** out, uint8_t g2_out[64], uint8_t s_g2_out[64]) {
+  if (!data || !out || len < 4) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_read: null or truncated input");
+  uint32_t k;
+  memcpy(&k, data, 4);
+  if (k > 26) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "srs_read: k %u > 26", k);
+  const size_t n = (size_t)1 << k;
+  if (len < zk_srs_serialized_size(k)) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_read: %zu bytes given, %zu needed for k = %u", len, zk_srs_serialized_size(k), k);
+  char* ws = nullptr;
+  ZK_TRY(zk_ws_reserve(ctx, 3, 2 * n * 32 + 2 * n * sizeof(G1Affine) + 256, (void**)&ws));
+  uint8_t* d_in = (uint8_t*)ws;
+  G1Affine* pts = (G1Affine*)(ws + 2 * n * 32);
+  int* d_err = (int*)(ws + 2 * n * 32 + 2 * n * sizeof(G1Affine));
+  ZK_HIP(ctx, hipMemcpyAsync(d_in, data + 4, 2 * n * 32, hipMemcpyHostToDevice, ctx->stream));
+  ZK_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(int), ctx->stream));
+  ZK_LAUNCH(ctx, "g1_decompress", g1_decompress_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, d_in, pts, 2 * n, d_err);
+  int herr = 0;
+  ZK_HIP(ctx, hipMemcpyAsync(&herr, d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (herr) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_read: invalid point encoding (not on the curve or x >= q)");
+  if (g2_out) memcpy(g2_out, data + 4 + 2 * n * 32, 64);
+  if (s_g2_out) memcpy(s_g2_out, data + 4 + 2 * n * 32 + 64, 64);
+  return srs_build(ctx, pts, pts + n, true, k, out);
+}
+
 int zk_srs_setup(amdzk_ctx* ctx, uint32_t k, const uint64_t s_mont[4], const uint64_t omega_mont[4], amdzk_srs** out,
                  uint64_t* g_out, uint64_t* g_lagrange_out) {
   if (k > 26) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "srs_setup: k %u > 26", k);

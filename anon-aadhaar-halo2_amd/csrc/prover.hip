@@ -98,6 +98,26 @@ std::array<uint64_t, 4> canon(const Fr& a) {
 
 }  // namespace
 
+// Source of the prover's Fr::random draws, in upstream's draw order: either ChaCha20Rng::seed_from_u64
+// replayed here, or scalars the caller drew from its own RngCore (amdzk_create_proof_scalars).
+struct RandomSource {
+  zkhost::ChaCha20Rng* rng = nullptr;
+  const uint64_t* scalars = nullptr;
+  size_t count = 0, used = 0;
+  bool exhausted = false;
+  Fr fr() {
+    if (rng) return rng->fr();
+    if (used >= count) {
+      exhausted = true;
+      return Fr::zero();
+    }
+    Fr r;
+    memcpy(r.l, scalars + 4 * used, 32);
+    used++;
+    return r;
+  }
+};
+
 struct amdzk_pk {
   uint32_t k = 0, ek = 0, bf = 0, degree = 0, F = 0, A = 0, I = 0, S = 0, L = 0, nsets = 0, chunk = 0, qdeg = 0;
   size_t n = 0, ext = 0;
@@ -941,6 +961,34 @@ int amdzk_pk_commitments(const amdzk_pk* pk, uint64_t* fixed_out /* F x 8 */, ui
 int amdzk_create_proof_ex(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances, const size_t* instance_lens, const void* d_advice,
                           size_t advice_stride, uint64_t rng_seed, int transcript_kind, uint8_t* proof_out, size_t proof_cap,
                           size_t* proof_len);
+static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances, const size_t* instance_lens, const void* d_advice,
+                             size_t advice_stride, RandomSource& rng, int transcript_kind, uint8_t* proof_out, size_t proof_cap,
+                             size_t* proof_len);
+
+// Number of Fr::random draws one create_proof makes for this key:
+// advice tails + advice blinds, per lookup 2 tails + 2 blinds, per permutation set tail + blind,
+// per lookup product tail + blind, the random polynomial + blind, the h-piece blinds.
+size_t amdzk_proof_random_count(const amdzk_pk* pk) {
+  if (!pk) return 0;
+  const size_t bf = pk->bf;
+  return (size_t)pk->A * (bf + 1) + pk->A + (size_t)pk->L * (2 * (bf + 1) + 2) + (size_t)pk->nsets * (bf + 1) + (size_t)pk->L * (bf + 1) +
+         pk->n + 1 + pk->qdeg;
+}
+
+// create_proof with the caller's randomness: `scalars` = amdzk_proof_random_count(pk) Fr elements
+// (Montgomery), drawn by the caller with Fr::random(&mut rng) in order.
+int amdzk_create_proof_scalars(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances, const size_t* instance_lens,
+                               const void* d_advice, size_t advice_stride, const uint64_t* scalars, size_t scalar_count, int transcript_kind,
+                               uint8_t* proof_out, size_t proof_cap, size_t* proof_len) {
+  if (!ctx) return AMDZK_E_INVALID;
+  if (!pk || !scalars) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof_scalars: null argument");
+  if (scalar_count < amdzk_proof_random_count(pk))
+    ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof_scalars: %zu scalars given, %zu needed", scalar_count, amdzk_proof_random_count(pk));
+  RandomSource rs;
+  rs.scalars = scalars;
+  rs.count = scalar_count;
+  return create_proof_impl(ctx, pk, instances, instance_lens, d_advice, advice_stride, rs, transcript_kind, proof_out, proof_cap, proof_len);
+}
 
 int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances, const size_t* instance_lens, const void* d_advice,
                        size_t advice_stride, uint64_t rng_seed, uint8_t* proof_out, size_t proof_cap, size_t* proof_len) {
@@ -952,12 +1000,21 @@ int amdzk_create_proof_ex(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* i
                           size_t advice_stride, uint64_t rng_seed, int transcript_kind, uint8_t* proof_out, size_t proof_cap,
                           size_t* proof_len) {
   if (!ctx) return AMDZK_E_INVALID;
+  ChaCha20Rng chacha(rng_seed);
+  RandomSource rs;
+  rs.rng = &chacha;
+  return create_proof_impl(ctx, pk, instances, instance_lens, d_advice, advice_stride, rs, transcript_kind, proof_out, proof_cap, proof_len);
+}
+
+static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances, const size_t* instance_lens, const void* d_advice,
+                             size_t advice_stride, RandomSource& rng, int transcript_kind, uint8_t* proof_out, size_t proof_cap,
+                             size_t* proof_len) {
+  if (!ctx) return AMDZK_E_INVALID;
   if (!pk || !proof_len || (pk->A && !d_advice)) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: null argument");
   const size_t n = pk->n, ext = pk->ext;
   const uint32_t F = pk->F, A = pk->A, I = pk->I, S = pk->S, L = pk->L, ns = pk->nsets, bf = pk->bf;
   const size_t usable = n - (bf + 1);
   if (advice_stride < n) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: advice stride < n");
-  ChaCha20Rng rng(rng_seed);
   zkhost::Blake2bWrite t_blake;
   zkhost::Keccak256Write t_keccak;
   if (transcript_kind != AMDZK_TRANSCRIPT_BLAKE2B && transcript_kind != AMDZK_TRANSCRIPT_KECCAK256_EVM)
@@ -1405,6 +1462,7 @@ int amdzk_create_proof_ex(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* i
     ZK_TRY(write_points(cm, "shplonk_h2"));
   }
   tick("shplonk");
+  if (rng.exhausted) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: ran out of caller-supplied random scalars");
   *proof_len = T.proof.size();
   if (proof_out) {
     if (proof_cap < T.proof.size()) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: proof buffer too small (%zu < %zu)", proof_cap, T.proof.size());

@@ -42,6 +42,9 @@ def lib():
         "amdzk_dev_memset": (i32, [vp, vp, i32, sz]),
         "amdzk_srs_upload": (i32, [vp, vp, vp, u32, C.POINTER(vp)]),
         "amdzk_srs_setup": (i32, [vp, u32, vp, C.POINTER(vp), vp, vp]),
+        "amdzk_srs_serialized_size": (sz, [u32]),
+        "amdzk_srs_write": (i32, [vp, vp, vp, vp, vp, sz]),
+        "amdzk_srs_read": (i32, [vp, vp, sz, C.POINTER(vp), vp, vp]),
         "amdzk_srs_free": (None, [vp, vp]),
         "amdzk_msm_g1": (i32, [vp, vp, i32, vp, sz, vp]),
         "amdzk_msm_g1_batch": (i32, [vp, vp, i32, C.POINTER(vp), sz, sz, vp]),
@@ -65,6 +68,8 @@ def lib():
         "amdzk_pk_commitments": (i32, [vp, vp, vp]),
         "amdzk_create_proof": (i32, [vp, vp, C.POINTER(vp), C.POINTER(sz), vp, sz, C.c_uint64, vp, sz, C.POINTER(sz)]),
         "amdzk_create_proof_ex": (i32, [vp, vp, C.POINTER(vp), C.POINTER(sz), vp, sz, C.c_uint64, i32, vp, sz, C.POINTER(sz)]),
+        "amdzk_proof_random_count": (sz, [vp]),
+        "amdzk_create_proof_scalars": (i32, [vp, vp, C.POINTER(vp), C.POINTER(sz), vp, sz, vp, sz, i32, vp, sz, C.POINTER(sz)]),
         "amdzk_timer_start": (i32, [vp]),
         "amdzk_timer_stop": (i32, [vp, C.POINTER(C.c_float)]),
         "amdzk_prof_enable": (i32, [vp, i32]),

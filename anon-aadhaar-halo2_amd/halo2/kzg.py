@@ -40,6 +40,29 @@ class ParamsKZG:
         self.h = h
         return self
 
+    def write(self, g2=bytes(64), s_g2=bytes(64)):
+        """ParamsKZG::write: serialized parameters as bytes (g2 / s_g2 are passed through)."""
+        size = self.ctx.L.amdzk_srs_serialized_size(self.k)
+        buf = (C.c_uint8 * size)()
+        a, b = (C.c_uint8 * 64)(*g2), (C.c_uint8 * 64)(*s_g2)
+        self.ctx._chk(self.ctx.L.amdzk_srs_write(self.ctx.h, self.h, a, b, buf, size))
+        return bytes(buf)
+
+    @classmethod
+    def read(cls, ctx, data):
+        """ParamsKZG::read: returns (params, g2 bytes, s_g2 bytes)."""
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        self.k = int.from_bytes(data[:4], "little")
+        self.n = 1 << self.k
+        self._g = self._gl = None
+        h = C.c_void_p()
+        g2, s_g2 = (C.c_uint8 * 64)(), (C.c_uint8 * 64)()
+        raw = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        ctx._chk(ctx.L.amdzk_srs_read(ctx.h, raw, len(data), C.byref(h), g2, s_g2))
+        self.h = h
+        return self, bytes(g2), bytes(s_g2)
+
     def commit(self, poly_coeff):
         """ParamsKZG::commit(poly, _blind): MSM with g[..len] (the blind is ignored for KZG)."""
         return arithmetic.best_multiexp(self.ctx, self.h, BASIS_G, poly_coeff)

@@ -370,3 +370,22 @@ def create_proof(ctx, pk, instances, d_advice, seed, advice_stride=None, transcr
     ctx._chk(ctx.L.amdzk_create_proof_ex(ctx.h, pk.h, ptrs, lens, d_advice.ptr if d_advice is not None else None, advice_stride or n,
                                          C.c_uint64(seed), transcript, buf, cap, C.byref(need)))
     return bytes(buf[: need.value])
+
+
+def proof_random_count(ctx, pk):
+    return int(ctx.L.amdzk_proof_random_count(pk.h))
+
+
+def create_proof_with_scalars(ctx, pk, instances, d_advice, scalars, advice_stride=None, transcript=TRANSCRIPT_BLAKE2B):
+    """create_proof with the caller's own RngCore: `scalars` = the Fr::random draws in upstream order."""
+    n = 1 << pk.desc["k"]
+    cols = [np.ascontiguousarray(c, dtype=np.uint64).reshape(-1, 4) for c in instances]
+    ptrs = (C.c_void_p * max(1, len(cols)))(*[c.ctypes.data if c.size else None for c in cols])
+    lens = (C.c_size_t * max(1, len(cols)))(*[c.shape[0] for c in cols])
+    sc = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    need = C.c_size_t(0)
+    cap = 1 << 20
+    buf = (C.c_uint8 * cap)()
+    ctx._chk(ctx.L.amdzk_create_proof_scalars(ctx.h, pk.h, ptrs, lens, d_advice.ptr if d_advice is not None else None, advice_stride or n,
+                                              sc.ctypes.data, sc.shape[0], transcript, buf, cap, C.byref(need)))
+    return bytes(buf[: need.value])

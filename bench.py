@@ -203,8 +203,10 @@ def main():
         else:  # h(X) evaluation: every coset column read once + h written
             alg_bytes = 32.0 * (n << 2) * (npolys + desc["num_fixed"] + S + 4 + 1) / launches
         avg_s = total_ms / launches * 1e-3
+        traffic, traffic_src = pmc_traffic(dom_name)
         roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(alg_bytes / avg_s / 1e9, 3), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                "unit": "GB/s", "frac": round(alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 6), "traffic": traffic,
+                "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(alg_bytes),
                 "avg_launch_ms": round(total_ms / launches, 4), "launches_per_step": launches,
                 "gpu_busy_ms_per_step": round(gpu_ms, 3), "wall_ms_profiled_step": round(wall_prof, 3),
                 "per_kernel_ms": {kname: round(v[1], 3) for kname, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
@@ -233,6 +235,24 @@ def main():
     params.free()
     for cx in ctxs:
         cx.close()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
+    command (profiles/r01h_kernel_summary.csv; counters cannot be read from inside the process).
+    FETCH_SIZE + WRITE_SIZE in KiB; the gfx950 x2 FETCH correction is for wide coalesced streams and is
+    NOT applied to this kernel's 64-byte random gathers (uncalibrated pattern, stated as such)."""
+    names = {"msm_accum_l1": "msm_accum_seg_kernel<true>", "expr_evaluate_h": "expr_eval_kernel"}
+    path = os.path.join(ROOT, "profiles", "r01h_kernel_summary.csv")
+    try:
+        import csv
+        for row in csv.DictReader(open(path)):
+            if row["kernel"] == names.get(kernel) and row["FETCH_SIZE_KiB_per_launch_raw"]:
+                b = (float(row["FETCH_SIZE_KiB_per_launch_raw"]) + float(row["WRITE_SIZE_KiB_per_launch_raw"])) * 1024
+                return round(b), "profiles/r01h_kernel_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, raw, per launch)"
+    except OSError:
+        pass
+    return None, None
 
 
 def cpu_baseline(adv, K, msm_cols, npolys):

@@ -83,6 +83,15 @@ int amdzk_srs_upload(amdzk_ctx* ctx, const uint64_t* g, const uint64_t* g_lagran
  * g_out / g_lagrange_out (2^k G1Affine each, host) may be NULL. */
 int amdzk_srs_setup(amdzk_ctx* ctx, uint32_t k, const uint64_t s[4], amdzk_srs** out, uint64_t* g_out,
                     uint64_t* g_lagrange_out);
+/* ParamsKZG::{write, read} [UP]: k (u32 LE) | n x g | n x g_lagrange (halo2curves 32-byte compressed
+ * G1: x little-endian, bit 7 of byte 31 = parity of y, all-zero = identity) | g2 | s_g2 (64 bytes each,
+ * opaque to the prover and passed through). Point (de)compression runs on the device; read rejects
+ * encodings that are not on the curve. */
+size_t amdzk_srs_serialized_size(uint32_t k);
+int amdzk_srs_write(amdzk_ctx* ctx, const amdzk_srs* srs, const uint8_t g2[64], const uint8_t s_g2[64],
+                    uint8_t* out, size_t cap);
+int amdzk_srs_read(amdzk_ctx* ctx, const uint8_t* data, size_t len, amdzk_srs** out,
+                   uint8_t g2_out[64], uint8_t s_g2_out[64]);
 void amdzk_srs_free(amdzk_ctx* ctx, amdzk_srs* srs);
 
 /* ---- MSM: replaces arithmetic::best_multiexp(coeffs, bases) as called from
@@ -194,6 +203,15 @@ int amdzk_create_proof_ex(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* i
                           const size_t* instance_lens, const void* d_advice, size_t advice_stride,
                           uint64_t rng_seed, int transcript_kind, uint8_t* proof_out,
                           size_t proof_cap, size_t* proof_len);
+/* For callers whose `R: RngCore` is not ChaCha20Rng::seed_from_u64: draw
+ * amdzk_proof_random_count(pk) scalars with Fr::random(&mut rng) and pass them (Montgomery Fr, in
+ * draw order); the prover consumes them exactly where upstream's create_proof draws. */
+size_t amdzk_proof_random_count(const amdzk_pk* pk);
+int amdzk_create_proof_scalars(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances,
+                               const size_t* instance_lens, const void* d_advice,
+                               size_t advice_stride, const uint64_t* scalars, size_t scalar_count,
+                               int transcript_kind, uint8_t* proof_out, size_t proof_cap,
+                               size_t* proof_len);
 
 /* ---- timing / profiling hooks used by bench.py (HIP events on this ctx's stream) ------------ */
 int amdzk_timer_start(amdzk_ctx* ctx);

@@ -146,3 +146,36 @@ def test_msm_k22_full_size_tau_identity(ctx, pkg, oracle):
         want = oracle.g1_mul_many(oracle.generator(), e.reshape(1, 4))[0]
         assert np.array_equal(got, want), kind
     params.free()
+
+
+def test_params_write_read_roundtrip(ctx, pkg, oracle):
+    """ParamsKZG::write / ::read: device compression matches the pure-Python encoder on every point,
+    read(write(p)) commits identically, and a corrupted encoding is rejected."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import plonk_ref as PR
+
+    k, tau = 8, 0x1234567890ABCDEF1234567
+    n = 1 << k
+    params = pkg.kzg.ParamsKZG.setup(ctx, k, zu.fr_from_int(tau), want_host_copy=True)
+    g2, s_g2 = bytes(range(64)), bytes(range(64, 128))
+    blob = params.write(g2, s_g2)
+    assert len(blob) == 4 + 2 * n * 32 + 128 and int.from_bytes(blob[:4], "little") == k
+    for i in (0, 1, 17, n - 1):
+        assert blob[4 + 32 * i:4 + 32 * (i + 1)] == PR.g1_compress(zu.point_to_ints(params._g[i]))
+        assert blob[4 + 32 * (n + i):4 + 32 * (n + i + 1)] == PR.g1_compress(zu.point_to_ints(params._gl[i]))
+    p2, g2b, sg2b = pkg.kzg.ParamsKZG.read(ctx, blob)
+    assert (g2b, sg2b) == (g2, s_g2)
+    c = zu.random_fr(n, seed=4)
+    assert np.array_equal(p2.commit(c), params.commit(c)) and np.array_equal(p2.commit_lagrange(c), params.commit_lagrange(c))
+    bad = bytearray(blob)
+    bad[4 + 32 * 5] ^= 1  # x of g[5] -> almost surely not on the curve (or a different point: then commits differ)
+    try:
+        p3, _, _ = pkg.kzg.ParamsKZG.read(ctx, bytes(bad))
+        assert not np.array_equal(p3.commit(c), params.commit(c))
+        p3.free()
+    except pkg.AmdzkError as e:
+        assert "invalid point" in str(e)
+    with pytest.raises(pkg.AmdzkError):
+        pkg.kzg.ParamsKZG.read(ctx, blob[:100])
+    p2.free(); params.free()

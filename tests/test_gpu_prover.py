@@ -126,3 +126,18 @@ def test_evm_proof_accepted_by_reference_solidity_verifier(ctx, pkg, plonk, orac
         bad[-1] ^= 1
         assert not CS.verify_proof(vk, bytes(bad), [], TAU)
         d_adv.free(); pk.free(); params.free()
+
+
+def test_caller_supplied_randomness_equals_seeded_rng(ctx, pkg, plonk, oracle):
+    """amdzk_create_proof_scalars with the scalars a ChaCha20Rng would have drawn gives the same bytes as
+    the seeded entry point (draw count and order = SURVEY.md Appendix A); too few scalars is an error."""
+    c = circuits.lookup_circuit(plonk, 6, seed=9)
+    params, pk, d_adv, inst = setup(ctx, pkg, plonk, oracle, c)
+    want = plonk.create_proof(ctx, pk, inst, d_adv, seed=77)
+    cnt = plonk.proof_random_count(ctx, pk)
+    rng = PR.ChaCha20Rng(77)
+    draws = zu.ints_to_fr(oracle, [rng.fr() for _ in range(cnt)])
+    assert plonk.create_proof_with_scalars(ctx, pk, inst, d_adv, draws) == want
+    with pytest.raises(pkg.AmdzkError):
+        plonk.create_proof_with_scalars(ctx, pk, inst, d_adv, draws[:-1])
+    d_adv.free(); pk.free(); params.free()
