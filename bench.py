@@ -88,9 +88,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a gfx950 GPU (there is no CPU fallback in the product path)")
+    # AMDZK_BENCH_FORCE_DEVICE / AMDZK_BENCH_BACKEND exist only to rehearse the N>1 code path on a
+    # one-GPU box (all ranks on device 0, gloo instead of RCCL); the driver never sets them.
+    if os.environ.get("AMDZK_BENCH_FORCE_DEVICE") is not None:
+        local_rank = int(os.environ["AMDZK_BENCH_FORCE_DEVICE"])
+    backend = os.environ.get("AMDZK_BENCH_BACKEND", "nccl")
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     P = args.concurrency
     if P <= 0:
         divs = [d for d in range(3, 7) if args.steps % d == 0]
@@ -169,12 +178,12 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         # the one exchange step: every rank's proofs (equal length) gathered on all ranks over RCCL.
         # global proof index = step*world + rank (round-robin, batch.shard_indices)
-        gathered = pkg.batch.gather_proofs(proofs, world * args.steps, device="cuda")
+        gathered = pkg.batch.gather_proofs(proofs, world * args.steps, device=coll_dev)
         assert len(gathered) == world * args.steps and all(len(p) == len(proofs[0]) for p in gathered)
 
     roof = cpu = None
