@@ -54,26 +54,26 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_kernel(ExprArgs a) {
   if (row >= a.nrows) return;  // domains smaller than one block (no barriers below, so an early exit is safe)
   Fr tos = Fr::zero();
   Fr h = Fr::zero();
-  const Fr yv = ld_fr(a.consts + a.y_const);
+  const Fr yv = a.y_ptr ? ld_fr(a.y_ptr) : Fr::zero();
   Fr hot[EXPR_HOT];
 #pragma unroll
   for (int i = 0; i < EXPR_HOT; i++) hot[i] = a.hot[i] != EXPR_NO_SLOT ? ld_fr(a.cols[a.hot[i]] + row) : Fr::zero();
   uint32_t sp = 0;  // elements on the stack, including tos
-  // operand prefetch state
-  Fr pre = Fr::zero();
-  uint32_t w = a.prog_len ? a.prog[0] : 0;
-  auto fetch = [&](uint32_t word) -> Fr {
-    const uint32_t arg = word & 0xffffffu;
-    const Fr* col = a.cols[arg >> 8];
-    const size_t idx = (row + (size_t)(int64_t)a.rot_off[arg & 0xff]) & a.mask;
-    return ld_fr(col + idx);
+  // Software pipeline over the (wave-uniform) instruction stream: while instruction pc executes, the
+  // operand of pc+1 is in flight (vector load) and instruction pc+2 is being fetched (scalar load).
+  const ExprInstr nop{0u, 0, nullptr};
+  auto fetch = [&](const ExprInstr& in) -> Fr {
+    const size_t idx = (row + (size_t)(int64_t)in.rot) & a.mask;
+    return ld_fr(in.ptr + idx);
   };
-  if (a.prog_len && op_reads_col(w >> 24)) pre = fetch(w);
+  ExprInstr cur = a.prog_len > 0 ? a.prog[0] : nop;
+  ExprInstr nxt = a.prog_len > 1 ? a.prog[1] : nop;
+  Fr pre = op_reads_col(cur.op_arg >> 24) ? fetch(cur) : Fr::zero();
   for (uint32_t pc = 0; pc < a.prog_len; pc++) {
-    const uint32_t op = w >> 24, arg = w & 0xffffffu;
+    const uint32_t op = cur.op_arg >> 24, arg = cur.op_arg & 0xffffffu;
     const Fr v = pre;  // operand of this instruction (if it has one), fetched one instruction ago
-    const uint32_t wn = pc + 1 < a.prog_len ? a.prog[pc + 1] : 0;
-    if (op_reads_col(wn >> 24)) pre = fetch(wn);
+    const ExprInstr nn = pc + 2 < a.prog_len ? a.prog[pc + 2] : nop;
+    if (op_reads_col(nxt.op_arg >> 24)) pre = fetch(nxt);
     switch (op) {
       case OP_PUSH_COL:
         if (sp > 0) stack[(sp - 1) * EXPR_THREADS + tid] = tos;
@@ -99,14 +99,14 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_kernel(ExprArgs a) {
         break;
       case OP_PUSH_CONST:
         if (sp > 0) stack[(sp - 1) * EXPR_THREADS + tid] = tos;
-        tos = ld_fr(a.consts + arg);
+        tos = ld_fr(cur.ptr);
         sp++;
         break;
       case OP_MUL_CONST:
-        tos = mul(tos, ld_fr(a.consts + arg));
+        tos = mul(tos, ld_fr(cur.ptr));
         break;
       case OP_ADD_CONST:
-        tos = add(tos, ld_fr(a.consts + arg));
+        tos = add(tos, ld_fr(cur.ptr));
         break;
       case OP_ADD:
         tos = add(stack[(sp - 2) * EXPR_THREADS + tid], tos);
@@ -139,7 +139,8 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_kernel(ExprArgs a) {
       default:
         break;
     }
-    w = wn;
+    cur = nxt;
+    nxt = nn;
   }
   if (a.h_out) st_fr(a.h_out + row, h);
 }

@@ -28,17 +28,24 @@ enum ExprOp : uint32_t {
 constexpr int EXPR_HOT = 4;
 constexpr uint32_t EXPR_NO_SLOT = 0xffffffffu;
 
+// One resolved instruction (16 bytes, fetched with a single scalar load): op << 24 | arg, the row
+// offset of the operand's rotation (already scaled for the domain), and the operand's base address —
+// a column for *_COL ops, the constant itself for *_CONST ops.
+struct ExprInstr {
+  uint32_t op_arg;
+  int32_t rot;
+  const bn254::Fr* ptr;
+};
+
 struct ExprArgs {
-  const uint32_t* prog;
+  const ExprInstr* prog;
   uint32_t prog_len;
-  const bn254::Fr* const* cols;  // slot -> column base (device array of device pointers)
-  const bn254::Fr* consts;       // constants table
-  const int32_t* rot_off;        // rotation-table: row offset (already scaled for the domain)
+  const bn254::Fr* const* cols;  // slot -> column base (device array of device pointers); used for the hot slots
   bn254::Fr* const* outs;        // OP_STORE targets
   bn254::Fr* h_out;              // OP_ACC result per row (may be null)
   size_t mask;                   // rows - 1
   size_t nrows;
-  uint32_t y_const;              // index of y in consts (OP_ACC)
+  const bn254::Fr* y_ptr;        // y (OP_ACC)
   uint32_t hot[EXPR_HOT];        // column slots held in registers for the whole row (rotation 0), or EXPR_NO_SLOT
 };
 

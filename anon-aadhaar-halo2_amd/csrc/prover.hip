@@ -65,7 +65,7 @@ struct Program {
   std::vector<uint32_t> words;
   uint32_t depth = 0, cur = 0;
   bool uses_hot = false;
-  uint32_t* d_words = nullptr;
+  ExprInstr* d_instr = nullptr;  // resolved instructions (device)
   void op(uint32_t o, uint32_t arg = 0) { words.push_back((o << 24) | (arg & 0xffffffu)); }
   void push() {
     cur++;
@@ -152,7 +152,6 @@ struct amdzk_pk {
   // programs
   Program prog_compress, prog_pfrac, prog_lfrac, prog_h;
   RotTable rots;
-  int32_t *d_rot_lag = nullptr, *d_rot_ext = nullptr;
   Fr* d_consts = nullptr;
   const Fr** d_cols_lag = nullptr;
   const Fr** d_cols_ext = nullptr;
@@ -160,6 +159,7 @@ struct amdzk_pk {
   Fr** d_outs_pfrac = nullptr;
   Fr** d_outs_lfrac = nullptr;
   std::vector<void*> allocs;
+  std::vector<const Fr*> h_cols_lag, h_cols_ext;  // host copies of the slot tables (program resolution)
   // pinned host staging (bump allocator, reset whenever the stream is known to be idle)
   char* pin = nullptr;
   size_t pin_cap = 0, pin_off = 0;
@@ -403,23 +403,42 @@ int emit_compressed(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, uint32_t first, u
   return AMDZK_OK;
 }
 
-int upload_program(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr) {
-  ZK_TRY(dalloc(ctx, pk, &pr.d_words, pr.words.size()));
-  return h2d(ctx, pr.d_words, pr.words.data(), pr.words.size() * 4);
+// Resolve slots / rotation indices / constant indices into addresses and row offsets for one domain
+// and upload the 16-byte instructions.
+int upload_program(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, bool extended) {
+  const std::vector<const Fr*>& cols = extended ? pk->h_cols_ext : pk->h_cols_lag;
+  const int32_t scale = extended ? (1 << (pk->ek - pk->k)) : 1;
+  std::vector<ExprInstr> ins(pr.words.size());
+  for (size_t i = 0; i < pr.words.size(); i++) {
+    const uint32_t w = pr.words[i], op = w >> 24, arg = w & 0xffffffu;
+    ins[i].op_arg = w;
+    ins[i].rot = 0;
+    ins[i].ptr = nullptr;
+    if (op == OP_PUSH_COL || op == OP_MUL_COL || op == OP_ADD_COL || op == OP_SUB_COL) {
+      if ((arg >> 8) >= cols.size() || (arg & 0xff) >= pk->rots.rots.size()) ZK_FAIL(ctx, AMDZK_E_INVALID, "program: bad column operand");
+      ins[i].ptr = cols[arg >> 8];
+      ins[i].rot = pk->rots.rots[arg & 0xff] * scale;
+    } else if (op == OP_PUSH_CONST || op == OP_MUL_CONST || op == OP_ADD_CONST) {
+      if (arg >= pk->consts.size()) ZK_FAIL(ctx, AMDZK_E_INVALID, "program: bad constant operand");
+      ins[i].ptr = pk->d_consts + arg;
+    }
+  }
+  ZK_TRY(dalloc(ctx, pk, &pr.d_instr, ins.size()));
+  ZK_TRY(h2d(ctx, pr.d_instr, ins.data(), ins.size() * sizeof(ExprInstr)));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `ins` is a host temporary
+  return AMDZK_OK;
 }
 
 int run_program(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, bool extended, Fr* const* d_outs, Fr* h_out, const char* name) {
   ExprArgs a;
-  a.prog = pr.d_words;
+  a.prog = pr.d_instr;
   a.prog_len = (uint32_t)pr.words.size();
   a.cols = extended ? pk->d_cols_ext : pk->d_cols_lag;
-  a.consts = pk->d_consts;
-  a.rot_off = extended ? pk->d_rot_ext : pk->d_rot_lag;
   a.outs = d_outs;
   a.h_out = h_out;
   a.nrows = extended ? pk->ext : pk->n;
   a.mask = a.nrows - 1;
-  a.y_const = pk->c_y;
+  a.y_ptr = pk->d_consts + pk->c_y;
   for (int i = 0; i < EXPR_HOT; i++) a.hot[i] = EXPR_NO_SLOT;
   if (extended && pr.uses_hot) {
     a.hot[0] = pk->se_l0();
@@ -708,6 +727,8 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
     ex[pk->se_llast()] = pk->llast_c;
     ex[pk->se_lactive()] = pk->lactive_c;
     ex[pk->se_x()] = pk->x_coset;
+    pk->h_cols_lag = lag;
+    pk->h_cols_ext = ex;
     KG_TRY(dalloc(ctx, pk, &pk->d_cols_lag, lag.size()));
     KG_TRY(dalloc(ctx, pk, &pk->d_cols_ext, ex.size()));
     KG_TRY(h2d(ctx, pk->d_cols_lag, lag.data(), lag.size() * sizeof(Fr*)));
@@ -913,22 +934,13 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
     amdzk_pk_free(ctx, pk);
     ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "keygen: more than 255 distinct rotations");
   }
-  KG_TRY(upload_program(ctx, pk, pk->prog_compress));
-  KG_TRY(upload_program(ctx, pk, pk->prog_pfrac));
-  KG_TRY(upload_program(ctx, pk, pk->prog_lfrac));
-  KG_TRY(upload_program(ctx, pk, pk->prog_h));
-  {
-    std::vector<int32_t> rl(pk->rots.rots), re(pk->rots.rots);
-    const int32_t scale = 1 << (pk->ek - pk->k);
-    for (auto& v : re) v *= scale;
-    KG_TRY(dalloc(ctx, pk, &pk->d_rot_lag, rl.size()));
-    KG_TRY(dalloc(ctx, pk, &pk->d_rot_ext, re.size()));
-    KG_TRY(h2d(ctx, pk->d_rot_lag, rl.data(), rl.size() * 4));
-    KG_TRY(h2d(ctx, pk->d_rot_ext, re.data(), re.size() * 4));
-    KG_TRY(dalloc(ctx, pk, &pk->d_consts, pk->consts.size()));
-    KG_TRY(h2d(ctx, pk->d_consts, pk->consts.data(), pk->consts.size() * 32));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  }
+  KG_TRY(dalloc(ctx, pk, &pk->d_consts, pk->consts.size()));
+  KG_TRY(h2d(ctx, pk->d_consts, pk->consts.data(), pk->consts.size() * 32));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  KG_TRY(upload_program(ctx, pk, pk->prog_compress, false));
+  KG_TRY(upload_program(ctx, pk, pk->prog_pfrac, false));
+  KG_TRY(upload_program(ctx, pk, pk->prog_lfrac, false));
+  KG_TRY(upload_program(ctx, pk, pk->prog_h, true));
   // l_active coset = 1 - (l_last + l_blind): lactive_c holds l_blind's coset; tiny one-off program
   {
     Program pr;
@@ -936,7 +948,7 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
     pr.op(OP_SUB_COL, COL(pk->se_llast(), r0));
     pr.op(OP_SUB_COL, COL(pk->se_lactive(), r0));
     pr.op(OP_STORE, 0); pr.pop();
-    KG_TRY(upload_program(ctx, pk, pr));
+    KG_TRY(upload_program(ctx, pk, pr, true));
     Fr** d_out = nullptr;
     KG_TRY(dalloc(ctx, pk, &d_out, 1));
     Fr* tgt = pk->lactive_c;
