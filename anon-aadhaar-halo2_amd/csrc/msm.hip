@@ -285,20 +285,6 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_accum_seg_kernel(AccArgs a) {
   st_x(out + off_out[b] + (t - off_in[b] / a.T), acc);
 }
 
-// Final level: one thread per bucket folds whatever is left and writes the dense bucket array.
-__global__ __launch_bounds__(MSM_THREADS) void msm_accum_final_kernel(const uint32_t* off_in_all,
-                                                                       uint32_t nb, const G1X* in_list,
-                                                                       size_t in_cap, G1X* dense) {
-  const uint32_t col = blockIdx.y;
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nb) return;
-  const uint32_t* off_in = off_in_all + (size_t)col * (nb + 1);
-  const G1X* in = in_list + (size_t)col * in_cap;
-  G1X acc = G1X::inf();
-  for (uint32_t e = off_in[b]; e < off_in[b + 1]; e++) acc = x_add(acc, ld_x(in + e));
-  st_x(dense + (size_t)col * nb + b, acc);
-}
-
 // ------------------------------------------------------------------ wavefront reductions
 __device__ __forceinline__ Fq shfl_xor_fq(const Fq& v, int m) {
   Fq r;
@@ -319,6 +305,33 @@ __device__ __forceinline__ G1X wave_sum(G1X v) {
 #pragma unroll 1
   for (int m = 32; m >= 1; m >>= 1) v = x_add(v, shfl_xor_x(v, m));
   return v;
+}
+
+// Final level: one lane per bucket folds whatever is left and writes the dense bucket array. A bucket
+// that still holds more than FINAL_SERIAL partial sums (a witness column where one value dominates)
+// is finished by the whole wavefront: lanes take strided shares, then a shuffle-tree sum.
+constexpr uint32_t FINAL_SERIAL = 6;
+__global__ __launch_bounds__(64) void msm_accum_final_kernel(const uint32_t* off_in_all, uint32_t nb, const G1X* in_list, size_t in_cap,
+                                                             G1X* dense) {
+  const uint32_t col = blockIdx.y, lane = threadIdx.x;
+  const uint32_t b = blockIdx.x * 64 + lane;  // nb is a multiple of 64
+  const uint32_t* off_in = off_in_all + (size_t)col * (nb + 1);
+  const G1X* in = in_list + (size_t)col * in_cap;
+  const uint32_t lo = off_in[b], hi = off_in[b + 1];
+  const uint32_t serial_end = min(hi, lo + FINAL_SERIAL);
+  G1X acc = G1X::inf();
+  for (uint32_t e = lo; e < serial_end; e++) acc = x_add(acc, ld_x(in + e));
+  unsigned long long heavy = __ballot(hi > serial_end);
+  while (heavy) {
+    const int src = __ffsll((long long)heavy) - 1;
+    heavy &= heavy - 1;
+    const uint32_t h_lo = __shfl(serial_end, src, 64), h_hi = __shfl(hi, src, 64);
+    G1X part = G1X::inf();
+    for (uint32_t e = h_lo + lane; e < h_hi; e += 64) part = x_add(part, ld_x(in + e));
+    part = wave_sum(part);
+    if ((int)lane == src) acc = x_add(acc, part);
+  }
+  st_x(dense + (size_t)col * nb + b, acc);
 }
 
 // rows[col][g] = sum_r dense[col][64g + r]   (one wave per g)
@@ -783,8 +796,8 @@ int zk_msm_dev_xyzz(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const Fr* d
     else
       ZK_LAUNCH(ctx, "msm_accum_fold", msm_accum_seg_kernel<false>, grid, dim3(MSM_THREADS), 0, a);
   }
-  ZK_LAUNCH(ctx, "msm_accum_final", msm_accum_final_kernel, dim3((nb + MSM_THREADS - 1) / MSM_THREADS, (unsigned)ncols),
-            dim3(MSM_THREADS), 0, off[NLEV], nb, list[NLEV], cap[NLEV], dense);
+  ZK_LAUNCH(ctx, "msm_accum_final", msm_accum_final_kernel, dim3(nb / 64, (unsigned)ncols), dim3(64), 0, off[NLEV], nb, list[NLEV], cap[NLEV],
+            dense);
   ZK_LAUNCH(ctx, "msm_rowcol", msm_rowcol_kernel, dim3((unsigned)(G + 64), (unsigned)ncols), dim3(64), 0, dense, nb, rows, cols);
   const unsigned fold_threads = G > 64 ? (unsigned)G : 64u;
   ZK_LAUNCH(ctx, "msm_fold", msm_fold_kernel, dim3((unsigned)ncols), dim3(fold_threads), 0, rows, cols, nb, outp);

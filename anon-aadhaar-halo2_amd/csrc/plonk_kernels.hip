@@ -297,15 +297,21 @@ __global__ void sub_low_kernel(Fr* a, const Fr* low, uint32_t m) {
 
 // ------------------------------------------------------------------------------ Kate division
 // In place: a(X) of n coefficients -> q(X) = (a(X) - a(b)) / (X - b), n coefficients with q[n-1] = 0.
-// q_i = sum_{j>i} a_j b^(j-i-1): a suffix recurrence, done as chunk Horner + LDS suffix scan + replay.
-// One workgroup per polynomial (grid.x = polynomial), roots[grid.x].
-__global__ __launch_bounds__(1024) void kate_div_kernel(Fr* const* polys, const Fr* roots, uint32_t n) {
-  __shared__ Fr S[1024];
-  const uint32_t t = threadIdx.x, T = blockDim.x;
-  Fr* a = polys[blockIdx.x];
-  const Fr b = ld_fr(roots + blockIdx.x);
-  const uint32_t E = (n + T - 1) / T;
-  const uint32_t s = t * E, e = s + E < n ? s + E : n;
+// q_i = sum_{j>i} a_j b^(j-i-1): a suffix recurrence. Each workgroup owns KD_BLOCK consecutive
+// coefficients: chunk Horner per thread + LDS suffix scan give the block's value relative to its start
+// (pass 1, `totals`); a per-polynomial serial pass turns the block values into the carry entering each
+// block from above (`carries`); pass 2 repeats the scan and replays every chunk with its carry.
+// grid = (blocks per polynomial, polynomials).
+constexpr uint32_t KD_THREADS = 256, KD_E = 8, KD_BLOCK = KD_THREADS * KD_E;
+
+template <bool WRITE>
+__global__ __launch_bounds__(KD_THREADS) void kate_div_kernel(Fr* const* polys, const Fr* roots, uint32_t n, uint32_t nblk, Fr* totals,
+                                                              const Fr* carries) {
+  __shared__ Fr S[KD_THREADS];
+  const uint32_t t = threadIdx.x, blk = blockIdx.x, poly = blockIdx.y;
+  Fr* a = polys[poly];
+  const Fr b = ld_fr(roots + poly);
+  const uint32_t s = blk * KD_BLOCK + t * KD_E, e = min(s + KD_E, n);
   Fr acc = Fr::zero();
   if (s < n) {
     acc = ld_fr(a + e - 1);
@@ -313,17 +319,22 @@ __global__ __launch_bounds__(1024) void kate_div_kernel(Fr* const* polys, const 
   }
   S[t] = acc;  // chunk value relative to its own start
   __syncthreads();
-  Fr pw = pow_u64(b, E);  // b^(E*d) for the current stride d
-  for (uint32_t d = 1; d < T; d <<= 1) {
-    Fr v = t + d < T ? S[t + d] : Fr::zero();
+  Fr pw = pow_u64(b, KD_E);  // b^(E*d) for the current stride d
+  for (uint32_t d = 1; d < KD_THREADS; d <<= 1) {
+    Fr v = t + d < KD_THREADS ? S[t + d] : Fr::zero();
     __syncthreads();
     S[t] = add(S[t], mul(pw, v));
     __syncthreads();
     pw = sqr(pw);
   }
+  if (!WRITE) {
+    if (t == 0) st_fr(totals + (size_t)poly * nblk + blk, S[0]);
+    return;
+  }
   if (s < n) {
-    Fr prev = t + 1 < T ? S[t + 1] : Fr::zero();  // carry entering this chunk from above
-    // chunks past the end contributed zero, and e may be short of s+E only in the last live chunk
+    // carry entering this chunk: later chunks of this block + the carry entering the block, moved down
+    Fr prev = t + 1 < KD_THREADS ? S[t + 1] : Fr::zero();
+    if (carries) prev = add(prev, mul(pow_u64(b, (uint64_t)KD_E * (KD_THREADS - 1 - t)), ld_fr(carries + (size_t)poly * nblk + blk)));
     for (uint32_t j = e; j-- > s;) {
       Fr aj = ld_fr(a + j);
       st_fr(a + j, prev);
@@ -332,6 +343,17 @@ __global__ __launch_bounds__(1024) void kate_div_kernel(Fr* const* polys, const 
   }
 }
 
+// carries[blk] = sum_{j >= end of blk} a_j b^(j - end of blk) = totals[blk+1] + b^KD_BLOCK * carries[blk+1]
+__global__ void kate_carry_kernel(const Fr* totals, Fr* carries, const Fr* roots, uint32_t nblk, uint32_t npolys) {
+  const uint32_t poly = blockIdx.x * blockDim.x + threadIdx.x;
+  if (poly >= npolys) return;
+  const Fr bl = pow_u64(ld_fr(roots + poly), KD_BLOCK);
+  Fr c = Fr::zero();
+  for (uint32_t blk = nblk; blk-- > 0;) {
+    st_fr(carries + (size_t)poly * nblk + blk, c);
+    c = add(ld_fr(totals + (size_t)poly * nblk + blk), mul(bl, c));
+  }
+}
 
 // ------------------------------------------------------------------------------ lookup permutation
 // plonk::lookup::prover::permute_expression_pair on the device: keys are
@@ -546,9 +568,21 @@ int zk_sub_low(amdzk_ctx* ctx, Fr* d_a, const Fr* d_low, uint32_t m) {
 }
 
 int zk_kate_div(amdzk_ctx* ctx, Fr* const* d_polys, const Fr* d_roots, size_t npolys, uint32_t n) {
-  unsigned threads = n >= 1024 ? 1024 : (n >= 64 ? (unsigned)(n / 64 * 64 > 1024 ? 1024 : ((n + 63) / 64 * 64)) : 64);
-  if (threads > 1024) threads = 1024;
-  if (npolys) ZK_LAUNCH(ctx, "kate_div", kate_div_kernel, dim3((unsigned)npolys), dim3(threads), 0, d_polys, d_roots, n);
+  if (npolys == 0 || n == 0) return AMDZK_OK;
+  const uint32_t nblk = (n + KD_BLOCK - 1) / KD_BLOCK;
+  dim3 grid(nblk, (unsigned)npolys), block(KD_THREADS);
+  if (nblk == 1) {
+    ZK_LAUNCH(ctx, "kate_div", kate_div_kernel<true>, grid, block, 0, d_polys, d_roots, n, nblk, (Fr*)nullptr, (const Fr*)nullptr);
+    return AMDZK_OK;
+  }
+  Fr* tmp = nullptr;  // totals | carries
+  ZK_TRY(zk_ws_reserve(ctx, 4, 2 * npolys * nblk * sizeof(Fr), (void**)&tmp));
+  Fr* totals = tmp;
+  Fr* carries = tmp + npolys * nblk;
+  ZK_LAUNCH(ctx, "kate_div_totals", kate_div_kernel<false>, grid, block, 0, d_polys, d_roots, n, nblk, totals, (const Fr*)nullptr);
+  ZK_LAUNCH(ctx, "kate_div_carry", kate_carry_kernel, dim3((unsigned)((npolys + 63) / 64)), dim3(64), 0, totals, carries, d_roots, nblk,
+            (uint32_t)npolys);
+  ZK_LAUNCH(ctx, "kate_div", kate_div_kernel<true>, grid, block, 0, d_polys, d_roots, n, nblk, (Fr*)nullptr, (const Fr*)carries);
   return AMDZK_OK;
 }
 
