@@ -121,11 +121,13 @@ def main():
         ctx.sync()
         return t
 
+    mont = lambda v: np.array([((v << 256) % R >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
     s_int = 0x0123456789ABCDEF0123456789ABCDEF % R
-    s_mont = np.array([((s_int << 256) % R >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
-    params = pkg.kzg.ParamsKZG.setup(ctx, K, s_mont)
+    want_cpu = rank == 0 and not args.no_cpu_baseline
+    params = pkg.kzg.ParamsKZG.setup(ctx, K, mont(s_int), want_host_copy=want_cpu)
     fixed_host = to_mont_dev(c.fixed).cpu().numpy().view(np.uint64)
-    tr = np.array([1, 2, 3, 4], dtype=np.uint64)
+    tr_int = 0xA11CE
+    tr = mont(tr_int)
     pks = [plonk.ProvingKey(cx, params, desc, fixed_host, c.assembly.mapping, tr) for cx in ctxs]
     pk = pks[0]
     adv = to_mont_dev(c.advice)  # resident witness, (A, n, 4)
@@ -220,7 +222,8 @@ def main():
                 "gpu_busy_ms_per_step": round(gpu_ms, 3), "wall_ms_profiled_step": round(wall_prof, 3),
                 "per_kernel_ms": {kname: round(v[1], 3) for kname, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
         if not args.no_cpu_baseline:
-            cpu = cpu_baseline(adv, K, msm_cols, npolys)
+            gpu_proof = plonk.create_proof(ctx, pk, inst, d_adv, seed=424242)
+            cpu = cpu_baseline(c, s_int, tr_int, params, gpu_proof)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -264,44 +267,26 @@ def pmc_traffic(kernel):
     return None, None
 
 
-def cpu_baseline(adv, K, msm_cols, npolys):
-    """CPU leg: the oracle (C++ restatement of halo2's best_multiexp / best_fft, OpenMP) on a bounded
-    sample of one proof's MSM/NTT list — 4 MSMs on real witness columns, 2 on uniform columns, 4 iNTT,
-    4 coset NTT — scaled to the proof's counts. It covers ONLY the MSM/NTT part of create_proof
-    (no quotient evaluation, grand products or openings), so it understates the CPU prover's time.
-    The oracle is the measured baseline here, never the product path."""
-    import zkutil as zu
+def cpu_baseline(c, s_int, tr_int, params, gpu_proof):
+    """CPU leg: ONE full create_proof of the same circuit, witness, SRS and RNG seed on the host cores
+    with the oracle prover (oracle/plonk_fast.py: upstream's step order; every O(n) loop — Pippenger MSM
+    per commitment as halo2's best_multiexp, radix-2 FFTs, the h(X) evaluation, permutation / lookup
+    products, evaluations — in the C++ oracle under OpenMP; transcript, RNG and glue in Python, which
+    inflates the CPU time somewhat). Its proof must equal the GPU's byte for byte; keygen is excluded on
+    both sides. The oracle is the measured baseline here, never the product path."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import plonk_fast as PF
 
-    O = zu.Oracle()
-    n = 1 << K
-    bases = O.srs_powers(zu.fr_from_int(12345), 1 << 10)
-    bases = np.ascontiguousarray(np.tile(bases, (n >> 10, 1)))  # timing only: any on-curve points
-
-    def t_msm(col):
-        t0 = time.perf_counter()
-        O.best_multiexp(np.ascontiguousarray(col), bases)
-        return time.perf_counter() - t0
-
-    wit = [adv[i].cpu().numpy().view(np.uint64) for i in (0, 1, adv.shape[0] - 1, adv.shape[0] - 20)]
-    m_wit = sum(t_msm(w) for w in wit) / len(wit)
-    m_uni = sum(t_msm(zu.random_fr(n, seed=s)) for s in (1, 2)) / 2
-    od = zu.OracleDomain(O, 4, K)
-    cols = [zu.random_fr(n, seed=10 + s) for s in range(4)]
     t0 = time.perf_counter()
-    for col in cols:
-        od.lagrange_to_coeff(col)
-    t_intt = (time.perf_counter() - t0) / 4
+    fpk = PF.FastKey(c.desc, c.fixed, c.assembly.mapping, s_int, tr_int, msm_bases=(params._g, params._gl))
+    t_keygen = time.perf_counter() - t0
     t0 = time.perf_counter()
-    for col in cols:
-        od.coeff_to_extended(col)
-    t_ext = (time.perf_counter() - t0) / 4
-    a_cols = adv.shape[0]
-    per_proof = a_cols * m_wit + (msm_cols - a_cols) * m_uni + npolys * (t_intt + t_ext) + t_ext
-    return {"value": round(1.0 / per_proof, 5), "unit": "proofs/s", "cores": O.threads, "kind": "port",
-            "sample": "MSM+NTT portion only: 4 witness-column MSMs + 2 uniform MSMs + 4 iNTT + 4 coset NTT at k=%d with the C++ "
-                      "oracle (OpenMP, %d threads), scaled to the proof's %d MSMs / %d polynomials" % (K, O.threads, msm_cols, npolys),
-            "ms_per_msm": {"witness": round(m_wit * 1e3, 2), "uniform": round(m_uni * 1e3, 2)},
-            "ms_per_intt": round(t_intt * 1e3, 2), "ms_per_coset_ntt": round(t_ext * 1e3, 2)}
+    proof = PF.create_proof(fpk, c.instances, c.advice, seed=424242)
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 5), "unit": "proofs/s", "cores": PF.threads(), "kind": "port",
+            "sample": "1 full create_proof (same circuit/witness/SRS/seed as the GPU run) with the C++/OpenMP oracle prover, "
+                      "%d threads; Python transcript/RNG/glue included; keygen (%.0f s) excluded" % (PF.threads(), t_keygen),
+            "seconds_per_proof": round(dt, 2), "proof_bytes_equal_gpu": proof == gpu_proof}
 
 
 if __name__ == "__main__":

@@ -94,15 +94,23 @@ def test_rsa_sha256_shape_small_equals_oracle(ctx, pkg, plonk, oracle):
     d_adv.free(); pk.free(); params.free()
 
 
-def test_rsa_sha256_shape_k15_verifies(ctx, pkg, plonk, oracle):
+def test_rsa_sha256_shape_k15_bytes_equal_cpu_prover_and_verify(ctx, pkg, plonk, oracle):
     """Full budget of TestRSASignatureWithHashCircuit1 (/root/reference/src/lib.rs:263-274) at the
-    reference's k = 15: 112 advice, 24 lookups, 115 permutation columns."""
+    reference's k = 15: 112 advice, 24 lookups, 115 permutation columns. The MI355X's proof is byte
+    for byte the CPU oracle prover's (oracle/plonk_fast.py, same witness / SRS / seed) and verifies."""
+    import plonk_fast as PF
+
     c = circuits.rsa_sha256_shape(plonk, k=15)
     circuits.check_satisfied(c, rows=range(0, c.usable, 997))
     assert c.desc["num_advice"] == 112 and len(c.desc["lookups"]) == 24 and len(c.desc["permutation_columns"]) == 115
     params, pk, d_adv, inst = setup(ctx, pkg, plonk, oracle, c)
     proof = plonk.create_proof(ctx, pk, inst, d_adv, seed=2024)
     assert PR.verify_proof(vk_from_device(pk, c), c.instances, proof)
+    fpk = PF.FastKey(c.desc, c.fixed, c.assembly.mapping, TAU, 123456789)
+    f, p = pk.commitments()
+    assert [zu.point_to_ints(x) for x in f] == fpk.fixed_commitments
+    assert [zu.point_to_ints(x) for x in p] == fpk.permutation_commitments
+    assert proof == PF.create_proof(fpk, c.instances, c.advice, seed=2024)
     d_adv.free(); pk.free(); params.free()
 
 

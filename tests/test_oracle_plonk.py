@@ -122,3 +122,18 @@ def test_reference_solidity_verifier_accepts_square_circuit_proof(plonk):
         adv = [list(col) for col in c.advice]
         adv[1][0] += 1
         assert not CS.verify_proof(vk, PR.create_proof(pk, c.instances, adv, seed=11, transcript="evm"), [], TAU)
+
+
+def test_fast_cpu_prover_equals_reference_prover(plonk):
+    """oracle/plonk_fast.py (C++/OpenMP loops, used at the real size) produces exactly
+    oracle/plonk_ref.py's bytes (pure Python) for both transcripts."""
+    import plonk_fast as PF
+
+    cases = [circuits.square_circuit(plonk, 4), circuits.lookup_circuit(plonk, 6, seed=2),
+             circuits.rsa_sha256_shape(plonk, k=7, num_advice=5, num_lookup_advice=2, lookup_bits=5, num_spread=2, spread_bits=3)]
+    for c in cases:
+        opk = PR.keygen(c.desc, c.fixed, c.assembly.mapping, TAU, transcript_repr=99)
+        fpk = PF.FastKey(c.desc, c.fixed, c.assembly.mapping, TAU, 99)
+        assert fpk.fixed_commitments == opk.fixed_commitments and fpk.permutation_commitments == opk.permutation_commitments
+        for tr in ("blake2b", "evm"):
+            assert PF.create_proof(fpk, c.instances, c.advice, seed=5, transcript=tr) == PR.create_proof(opk, c.instances, c.advice, seed=5, transcript=tr)
