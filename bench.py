@@ -35,6 +35,9 @@ SHAPES = {
     "k15": dict(k=15, num_advice=80, num_lookup_advice=16, lookup_bits=12, num_spread=8, spread_bits=8),
     # BASELINE.json configs[1] "k~18": same area, 8x fewer gate columns
     "k18": dict(k=18, num_advice=10, num_lookup_advice=2, lookup_bits=12, num_spread=1, spread_bits=8),
+    # BASELINE.json configs[2]: the composite AadhaarQRVerifierCircuit budget (src/aadhaar_verifier_circuit.rs:49-56):
+    # k15 + IdentityCircuit + TimestampCircuit + SquareCircuit columns and gates
+    "full": dict(k=15, num_advice=80, num_lookup_advice=16, lookup_bits=12, num_spread=8, spread_bits=8, composite=True),
 }
 
 
@@ -107,11 +110,12 @@ def main():
     ctxs = [pkg.Context(local_rank) for _ in range(P)]
     ctx = ctxs[0]
 
-    shape = SHAPES[args.shape]
+    shape = dict(SHAPES[args.shape])
+    make_circuit = circuits.full_aadhaar_shape if shape.pop("composite", False) else circuits.rsa_sha256_shape
     K = shape["k"]
     n = 1 << K
     t_setup = time.perf_counter()
-    c = circuits.rsa_sha256_shape(plonk, seed=7 + rank, **shape)
+    c = make_circuit(plonk, seed=7 + rank, **shape)
     desc = c.desc
 
     def to_mont_dev(cols):
@@ -231,9 +235,9 @@ def main():
                 "value": round(world * args.steps / dt, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "u32x8 (254-bit Montgomery integers)", "data": "synthetic",
-                "config": {"workload": "create_proof, rsa_sha256_shape %s: %d advice, %d lookups, %d permutation columns, degree %d, "
+                "config": {"workload": "create_proof, %s %s: %d advice, %d lookups, %d permutation columns, degree %d, "
                                        "KZG/SHPLONK/Blake2b, witness resident"
-                                       % (args.shape, desc["num_advice"], len(desc["lookups"]), len(desc["permutation_columns"]), desc["cs_degree"]),
+                                       % (make_circuit.__name__, args.shape, desc["num_advice"], len(desc["lookups"]), len(desc["permutation_columns"]), desc["cs_degree"]),
                            "k": K, "extended_k": K + 2, "proof_bytes": len(proofs[-1]), "proofs_in_flight_per_gpu": P,
                            "single_proof_latency_ms": round(wall_prof, 3) if rank == 0 else None,
                            "parallelism": "independent proofs sharded across GPUs, %d in flight per GPU" % P,

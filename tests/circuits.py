@@ -126,9 +126,12 @@ def lookup_circuit(plonk, k=5, seed=1):
     return c
 
 
-def rsa_sha256_shape(plonk, k=15, seed=7, num_advice=80, num_lookup_advice=16, lookup_bits=12, num_spread=8, spread_bits=8):
+def rsa_sha256_shape(plonk, k=15, seed=7, num_advice=80, num_lookup_advice=16, lookup_bits=12, num_spread=8, spread_bits=8,
+                     configure_extra=None):
     """Synthetic witness of the reference circuit's shape. Values are built with numpy on canonical
-    integers (object arrays only where products are needed)."""
+    integers (object arrays only where products are needed). `configure_extra(cs)` may add further
+    sub-circuit configurations after this one (as AadhaarQRVerifierCircuit::configure does) and returns
+    the function that assigns their cells."""
     rnd = np.random.RandomState(seed)
     cs = plonk.ConstraintSystem()
     gate_cols = [cs.advice_column() for _ in range(num_advice)]
@@ -148,6 +151,7 @@ def rsa_sha256_shape(plonk, k=15, seed=7, num_advice=80, num_lookup_advice=16, l
     for dcol, scol in zip(sp_dense, sp_spread):
         cs.lookup(lambda m, dcol=dcol, scol=scol: [(m.query_advice(dcol, 0), m.query_fixed(t_dense, 0)),
                                                    (m.query_advice(scol, 0), m.query_fixed(t_spread, 0))])
+    synthesize_extra = configure_extra(cs) if configure_extra else None
     c = Circuit(cs, k)
     n, u = c.n, c.usable
     c.assembly = plonk.Assembly(n, len(cs.permutation_columns))
@@ -220,7 +224,66 @@ def rsa_sha256_shape(plonk, k=15, seed=7, num_advice=80, num_lookup_advice=16, l
         lc = lk_cols[i % num_lookup_advice]
         c.instances[1].append(c.advice[lc.index][20 + i])
         c.copy(inst[1], i, lc, 20 + i)
+    if synthesize_extra:
+        synthesize_extra(c)
     return c
+
+
+def full_aadhaar_shape(plonk, k=15, seed=7, signal=5, **kw):
+    """Column/gate budget of the composite AadhaarQRVerifierCircuit
+    (/root/reference/src/aadhaar_verifier_circuit.rs:49-56): the RSA-SHA256 shape, then
+      IdentityCircuit  (/root/reference/src/conditional_secrets.rs:81-190) 20 advice, 1 selector, 8 gates
+                       (12 polynomials: 4 booleanity, age/gender/pincode reveals, 5 state bytes),
+      TimestampCircuit (/root/reference/src/timestamp.rs:58-138) 7 advice columns no gate queries (its
+                       range gates are commented out there; its selector is never used in a gate, so
+                       halo2's selector compression gives it no fixed column and neither do we),
+      SquareCircuit    (/root/reference/src/signal.rs:27-76) 2 equality-enabled advice, 1 instance,
+                       1 selector, gate s*(a1 - a0^2).
+    Each sub-circuit assigns one row (row 0 of its own columns), as the reference's regions do."""
+
+    def configure_extra(cs):
+        # IdentityCircuit
+        names = ["reveal_age", "age", "qr_age", "reveal_gender", "gender", "qr_gender", "reveal_pincode", "pincode", "qr_pincode",
+                 "reveal_state"] + ["state%d" % i for i in range(5)] + ["qr_state%d" % i for i in range(5)]
+        idc = {nm: cs.advice_column() for nm in names}
+        s_id = cs.selector()
+        for nm in ("reveal_age", "reveal_gender", "reveal_pincode", "reveal_state"):
+            cs.create_gate(lambda m, nm=nm: [m.query_selector(s_id) * m.query_advice(idc[nm], 0)
+                                             * (m.query_advice(idc[nm], 0) - plonk.Expression.constant(1))])
+        cs.create_gate(lambda m: [m.query_selector(s_id) * (m.query_advice(idc["age"], 0)
+                                                            - m.query_advice(idc["reveal_age"], 0) * m.query_advice(idc["qr_age"], 0))])
+        cs.create_gate(lambda m: [m.query_selector(s_id) * (m.query_advice(idc["gender"], 0) - m.query_advice(idc["qr_gender"], 0))])
+        cs.create_gate(lambda m: [m.query_selector(s_id) * (m.query_advice(idc["pincode"], 0) - m.query_advice(idc["qr_pincode"], 0))])
+        cs.create_gate(lambda m: [m.query_selector(s_id) * (m.query_advice(idc["state%d" % i], 0) - m.query_advice(idc["qr_state%d" % i], 0))
+                                  for i in range(5)])
+        # TimestampCircuit: year, month, day, hour, minute, second, timestamp
+        ts = [cs.advice_column() for _ in range(7)]
+        # SquareCircuit
+        sq = [cs.advice_column(), cs.advice_column()]
+        sq_inst = cs.instance_column()
+        s_sq = cs.selector()
+        for col in sq + [sq_inst]:
+            cs.enable_equality(col)
+        cs.create_gate(lambda m: [m.query_selector(s_sq) * (m.query_advice(sq[1], 0) - m.query_advice(sq[0], 0) * m.query_advice(sq[0], 0))])
+
+        def synthesize(c):
+            c.fixed[s_id.index][0] = 1
+            vals = {"reveal_age": 1, "age": 1, "qr_age": 1, "reveal_gender": 1, "gender": 77, "qr_gender": 77,
+                    "reveal_pincode": 0, "pincode": 110051, "qr_pincode": 110051, "reveal_state": 1}
+            for i, ch in enumerate(b"Delhi"):
+                vals["state%d" % i] = vals["qr_state%d" % i] = ch
+            for nm, v in vals.items():
+                c.advice[idc[nm].index][0] = v
+            for col, v in zip(ts, (2019, 3, 8, 5, 30, 0, 1552023000)):
+                c.advice[col.index][0] = v
+            c.fixed[s_sq.index][0] = 1
+            c.advice[sq[0].index][0] = signal % R
+            c.advice[sq[1].index][0] = signal * signal % R
+            c.instances[sq_inst.index] = []
+
+        return synthesize
+
+    return rsa_sha256_shape(plonk, k=k, seed=seed, configure_extra=configure_extra, **kw)
 
 
 def check_satisfied(c, rows=None):

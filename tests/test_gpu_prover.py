@@ -114,6 +114,31 @@ def test_rsa_sha256_shape_k15_bytes_equal_cpu_prover_and_verify(ctx, pkg, plonk,
     d_adv.free(); pk.free(); params.free()
 
 
+def test_full_aadhaar_shape_equals_oracle(ctx, pkg, plonk, oracle):
+    """Composite AadhaarQRVerifierCircuit budget (/root/reference/src/aadhaar_verifier_circuit.rs:49-56,
+    BASELINE config 3): RSA shape + IdentityCircuit gates + 7 never-queried timestamp columns +
+    SquareCircuit. Small k: bytes equal the pure-Python oracle prover for both transcripts; k = 15 with the
+    full column budget (141 advice, 118 permutation columns): bytes equal the CPU oracle prover and verify."""
+    import plonk_fast as PF
+
+    c = circuits.full_aadhaar_shape(plonk, k=7, num_advice=5, num_lookup_advice=2, lookup_bits=5, num_spread=2, spread_bits=3)
+    params, pk, d_adv, inst = setup(ctx, pkg, plonk, oracle, c)
+    opk = PR.keygen(c.desc, c.fixed, c.assembly.mapping, TAU, transcript_repr=123456789)
+    assert plonk.create_proof(ctx, pk, inst, d_adv, seed=9) == PR.create_proof(opk, c.instances, c.advice, seed=9)
+    assert plonk.create_proof(ctx, pk, inst, d_adv, seed=9, transcript=plonk.TRANSCRIPT_KECCAK256_EVM) == \
+        PR.create_proof(opk, c.instances, c.advice, seed=9, transcript="evm")
+    d_adv.free(); pk.free(); params.free()
+
+    c = circuits.full_aadhaar_shape(plonk, k=15)
+    assert c.desc["num_advice"] == 141 and len(c.desc["lookups"]) == 24 and len(c.desc["permutation_columns"]) == 118
+    params, pk, d_adv, inst = setup(ctx, pkg, plonk, oracle, c)
+    proof = plonk.create_proof(ctx, pk, inst, d_adv, seed=77)
+    assert PR.verify_proof(vk_from_device(pk, c), c.instances, proof)
+    fpk = PF.FastKey(c.desc, c.fixed, c.assembly.mapping, TAU, 123456789)
+    assert proof == PF.create_proof(fpk, c.instances, c.advice, seed=77)
+    d_adv.free(); pk.free(); params.free()
+
+
 def test_evm_proof_accepted_by_reference_solidity_verifier(ctx, pkg, plonk, oracle):
     """Config 1/3 of BASELINE.json in the form the reference can check: the SquareCircuit
     (/root/reference/src/signal.rs) proved on the MI355X with the Keccak256/EVM transcript equals the

@@ -101,6 +101,32 @@ def test_rsa_shape_budget(plonk):
     assert full is not None
 
 
+SMALL = dict(num_advice=5, num_lookup_advice=2, lookup_bits=5, num_spread=2, spread_bits=3)
+
+
+def test_full_aadhaar_shape_budget_and_oracle_proof(plonk):
+    """Composite AadhaarQRVerifierCircuit budget (src/aadhaar_verifier_circuit.rs:49-56): on top of the
+    RSA shape, 20 + 7 + 2 advice, 12 more gate polynomials, one more instance column; the 7 timestamp
+    columns are committed but never queried. The oracle prover's proof verifies, and a broken
+    IdentityCircuit witness (gender != qr_data_gender) does not."""
+    base = circuits.rsa_sha256_shape(plonk, k=7, **SMALL)
+    c = circuits.full_aadhaar_shape(plonk, k=7, **SMALL)
+    circuits.check_satisfied(c)
+    assert c.desc["num_advice"] == base.desc["num_advice"] + 29
+    assert len(c.desc["gates"]) == len(base.desc["gates"]) + 12 + 1
+    assert c.desc["num_instance"] == 3 and c.desc["num_fixed"] == base.desc["num_fixed"] + 2
+    assert len(c.desc["permutation_columns"]) == len(base.desc["permutation_columns"]) + 3
+    queried = {col for col, _ in c.desc["advice_queries"]}
+    assert len(queried) == c.desc["num_advice"] - 7
+    pk = PR.keygen(c.desc, c.fixed, c.assembly.mapping, TAU, transcript_repr=5)
+    proof = PR.create_proof(pk, c.instances, c.advice, seed=3)
+    assert PR.verify_proof(pk, c.instances, proof)
+    adv = [list(col) for col in c.advice]
+    adv[base.desc["num_advice"] + 4][0] += 1  # IdentityCircuit.gender
+    with pytest.raises(AssertionError):
+        PR.verify_proof(pk, c.instances, PR.create_proof(pk, c.instances, adv, seed=3))
+
+
 def test_reference_solidity_verifier_accepts_square_circuit_proof(plonk):
     """The reference's own verifier — solidity_verifier_contract/contract.sol, restated statement by
     statement in oracle/contract_sol.py (pairing replaced by the known-trapdoor check) — accepts the
@@ -130,7 +156,7 @@ def test_fast_cpu_prover_equals_reference_prover(plonk):
     import plonk_fast as PF
 
     cases = [circuits.square_circuit(plonk, 4), circuits.lookup_circuit(plonk, 6, seed=2),
-             circuits.rsa_sha256_shape(plonk, k=7, num_advice=5, num_lookup_advice=2, lookup_bits=5, num_spread=2, spread_bits=3)]
+             circuits.rsa_sha256_shape(plonk, k=7, **SMALL), circuits.full_aadhaar_shape(plonk, k=7, **SMALL)]
     for c in cases:
         opk = PR.keygen(c.desc, c.fixed, c.assembly.mapping, TAU, transcript_repr=99)
         fpk = PF.FastKey(c.desc, c.fixed, c.assembly.mapping, TAU, 99)
