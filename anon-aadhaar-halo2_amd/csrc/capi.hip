@@ -17,6 +17,9 @@ int zk_msm_finish(amdzk_ctx* ctx, const G1X* d_res, size_t ncols, uint64_t* out_
 int zk_srs_setup(amdzk_ctx* ctx, uint32_t k, const uint64_t s_mont[4], const uint64_t omega_mont[4], amdzk_srs** out, uint64_t* g_out,
                  uint64_t* g_lagrange_out);
 size_t zk_srs_serialized_size(uint32_t k);
+int zk_g_to_lagrange(amdzk_ctx* ctx, const uint64_t* g, uint32_t k, const uint64_t omega_inv[4], const uint64_t n_inv[4], uint64_t* out);
+int zk_srs_downsize(amdzk_ctx* ctx, const amdzk_srs* srs, uint32_t new_k, const uint64_t omega_inv[4], const uint64_t n_inv[4], amdzk_srs** out);
+int zk_srs_get(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, uint64_t* out);
 int zk_srs_write(amdzk_ctx* ctx, const amdzk_srs* s, const uint8_t g2[64], const uint8_t s_g2[64], uint8_t* out, size_t cap);
 int zk_srs_read(amdzk_ctx* ctx, const uint8_t* data, size_t len, amdzk_srs** out, uint8_t g2_out[64], uint8_t s_g2_out[64]);
 extern "C" int amdzk_domain_new(amdzk_ctx* ctx, uint32_t j, uint32_t k, struct amdzk_domain** out);
@@ -189,6 +192,30 @@ int amdzk_srs_setup(amdzk_ctx* ctx, uint32_t k, const uint64_t s[4], amdzk_srs**
   amdzk_domain_constant(dom, 0, omega);
   amdzk_domain_free(ctx, dom);
   return zk_srs_setup(ctx, k, s, omega, out, g_out, g_lagrange_out);
+}
+static int fft_constants(amdzk_ctx* ctx, uint32_t k, uint64_t omega_inv[4], uint64_t n_inv[4]) {
+  amdzk_domain* dom = nullptr;
+  ZK_TRY(amdzk_domain_new(ctx, 3, k, &dom));
+  amdzk_domain_constant(dom, 1, omega_inv);
+  amdzk_domain_constant(dom, 6, n_inv);
+  amdzk_domain_free(ctx, dom);
+  return AMDZK_OK;
+}
+int amdzk_g_to_lagrange(amdzk_ctx* ctx, const uint64_t* g, uint32_t k, uint64_t* g_lagrange_out) {
+  if (!ctx) return AMDZK_E_INVALID;
+  uint64_t wi[4], ni[4];
+  ZK_TRY(fft_constants(ctx, k, wi, ni));
+  return zk_g_to_lagrange(ctx, g, k, wi, ni, g_lagrange_out);
+}
+int amdzk_srs_downsize(amdzk_ctx* ctx, const amdzk_srs* srs, uint32_t new_k, amdzk_srs** out) {
+  if (!ctx) return AMDZK_E_INVALID;
+  uint64_t wi[4], ni[4];
+  ZK_TRY(fft_constants(ctx, new_k, wi, ni));
+  return zk_srs_downsize(ctx, srs, new_k, wi, ni, out);
+}
+int amdzk_srs_get(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, uint64_t* out) {
+  if (!ctx) return AMDZK_E_INVALID;
+  return zk_srs_get(ctx, srs, basis, out);
 }
 size_t amdzk_srs_serialized_size(uint32_t k) { return zk_srs_serialized_size(k); }
 int amdzk_srs_write(amdzk_ctx* ctx, const amdzk_srs* srs, const uint8_t g2[64], const uint8_t s_g2[64], uint8_t* out, size_t cap) {

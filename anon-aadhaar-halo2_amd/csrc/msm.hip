@@ -695,6 +695,120 @@ int zk_srs_setup(amdzk_ctx* ctx, uint32_t k, const uint64_t s_mont[4], const uin
   return srs_build(ctx, g, gl, true, k, out);
 }
 
+// ---- arithmetic::g_to_lagrange(g, k) and ParamsKZG::downsize(k) [UP]:
+// g_lagrange = (1/n) * FFT_{omega^-1}(g) over the group — the same radix-2 network as the scalar NTT with
+// every twiddle product a G1 scalar multiplication. Decimation in frequency on XYZZ points in HBM
+// (k launches, one butterfly per thread), then one pass that scales by 1/n, normalises to affine and
+// undoes the bit reversal. Start-up work only: n/2 * log n + n scalar multiplications.
+namespace {
+// canon: canonical (non-Montgomery) scalar; MSB-first double-and-add.
+__device__ G1X x_scalar_mul(const G1X& p, const Fr& canon) {
+  G1X acc = G1X::inf();
+  int top = -1;
+  for (int limb = 7; limb >= 0 && top < 0; limb--)
+    if (canon.l[limb]) top = limb * 32 + 31 - __clz(canon.l[limb]);
+#pragma unroll 1
+  for (int b = top; b >= 0; b--) {
+    acc = x_dbl(acc);
+    if ((canon.l[b >> 5] >> (b & 31)) & 1) acc = x_add(acc, p);
+  }
+  return acc;
+}
+__global__ __launch_bounds__(256) void ecfft_load_kernel(const G1Affine* g, G1X* a, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) st_x(a + i, x_from_affine(ld_aff(g + i)));
+}
+// One DIF round: (u, v) at distance half -> (u + v, (u - v) * w^(pos << tw_shift)).
+__global__ __launch_bounds__(256) void ecfft_round_kernel(G1X* a, size_t n, uint32_t half_log, const Fr* tw, uint32_t tw_shift) {
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n / 2) return;
+  const size_t half = (size_t)1 << half_log, pos = j & (half - 1);
+  const size_t i0 = ((j >> half_log) << (half_log + 1)) + pos, i1 = i0 + half;
+  G1X u = ld_x(a + i0), v = ld_x(a + i1);
+  st_x(a + i0, x_add(u, v));
+  G1X d = x_add(u, x_neg(v));
+  if (pos != 0) {
+    const uint4* q = reinterpret_cast<const uint4*>(tw + (pos << tw_shift));
+    uint4 lo = q[0], hi = q[1];
+    Fr w;
+    w.l[0] = lo.x; w.l[1] = lo.y; w.l[2] = lo.z; w.l[3] = lo.w;
+    w.l[4] = hi.x; w.l[5] = hi.y; w.l[6] = hi.z; w.l[7] = hi.w;
+    d = x_scalar_mul(d, from_mont(w));
+  }
+  st_x(a + i1, d);
+}
+__global__ __launch_bounds__(256) void ecfft_finish_kernel(const G1X* a, G1Affine* out, size_t n, uint32_t k, Fr ninv_canon) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  size_t r = k ? (size_t)(__brevll((unsigned long long)i) >> (64 - k)) : 0;
+  st_aff(out + r, x_to_affine(x_scalar_mul(ld_x(a + i), ninv_canon)));
+}
+
+// d_g, d_out: n affine points on the device (may not alias); d_xyzz: n G1X; d_tw: max(n/2, 1) Fr.
+int ecfft_to_lagrange(amdzk_ctx* ctx, const G1Affine* d_g, uint32_t k, const Fr& omega_inv, const Fr& n_inv, G1X* d_xyzz, Fr* d_tw,
+                      G1Affine* d_out) {
+  const size_t n = (size_t)1 << k;
+  dim3 eg((unsigned)((n + 255) / 256)), hg((unsigned)((n / 2 + 255) / 256)), eb(256);
+  ZK_LAUNCH(ctx, "ecfft_load", ecfft_load_kernel, eg, eb, 0, d_g, d_xyzz, n);
+  if (k > 0) {
+    const uint32_t chunk = 64;
+    dim3 pg((unsigned)(((n / 2 + chunk - 1) / chunk + 63) / 64)), pb(64);
+    ZK_LAUNCH(ctx, "srs_powers", powers_kernel, pg, pb, 0, d_tw, omega_inv, n / 2, chunk);
+    for (uint32_t s = 0; s < k; s++)
+      ZK_LAUNCH(ctx, "ecfft_round", ecfft_round_kernel, hg, eb, 0, d_xyzz, n, k - 1 - s, (const Fr*)d_tw, s);
+  }
+  ZK_LAUNCH(ctx, "ecfft_finish", ecfft_finish_kernel, eg, eb, 0, (const G1X*)d_xyzz, d_out, n, k, from_mont(n_inv));
+  return AMDZK_OK;
+}
+}  // namespace
+
+int zk_g_to_lagrange(amdzk_ctx* ctx, const uint64_t* g, uint32_t k, const uint64_t omega_inv[4], const uint64_t n_inv[4], uint64_t* out) {
+  if (!g || !out) ZK_FAIL(ctx, AMDZK_E_INVALID, "g_to_lagrange: null argument");
+  if (k > 26) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "g_to_lagrange: k %u > 26", k);
+  const size_t n = (size_t)1 << k;
+  Fr wi, ni;
+  memcpy(wi.l, omega_inv, 32);
+  memcpy(ni.l, n_inv, 32);
+  char* ws = nullptr;  // g[n] | gl[n] | xyzz[n] | tw[n/2]
+  ZK_TRY(zk_ws_reserve(ctx, 3, 2 * n * sizeof(G1Affine) + n * sizeof(G1X) + (n / 2 + 1) * sizeof(Fr), (void**)&ws));
+  G1Affine* dg = (G1Affine*)ws;
+  G1Affine* dl = dg + n;
+  G1X* dx = (G1X*)(dl + n);
+  Fr* tw = (Fr*)(dx + n);
+  ZK_HIP(ctx, hipMemcpyAsync(dg, g, n * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream));
+  ZK_TRY(ecfft_to_lagrange(ctx, dg, k, wi, ni, dx, tw, dl));
+  ZK_HIP(ctx, hipMemcpyAsync(out, dl, n * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AMDZK_OK;
+}
+
+int zk_srs_downsize(amdzk_ctx* ctx, const amdzk_srs* srs, uint32_t new_k, const uint64_t omega_inv[4], const uint64_t n_inv[4],
+                    amdzk_srs** out) {
+  if (!srs || !out) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_downsize: null argument");
+  if (new_k > srs->k) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_downsize: k %u > params k %u", new_k, srs->k);
+  if (!srs->table[0]) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_downsize: params hold no monomial basis g");
+  const size_t n = (size_t)1 << new_k;
+  Fr wi, ni;
+  memcpy(wi.l, omega_inv, 32);
+  memcpy(ni.l, n_inv, 32);
+  char* ws = nullptr;  // gl[n] | xyzz[n] | tw[n/2]
+  ZK_TRY(zk_ws_reserve(ctx, 3, n * sizeof(G1Affine) + n * sizeof(G1X) + (n / 2 + 1) * sizeof(Fr), (void**)&ws));
+  G1Affine* dl = (G1Affine*)ws;
+  G1X* dx = (G1X*)(dl + n);
+  Fr* tw = (Fr*)(dx + n);
+  ZK_TRY(ecfft_to_lagrange(ctx, srs->table[0], new_k, wi, ni, dx, tw, dl));  // window 0 of the table is g itself
+  return srs_build(ctx, srs->table[0], dl, true, new_k, out);
+}
+
+// ParamsKZG::get_g() / g_lagrange: the affine bases back on the host.
+int zk_srs_get(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, uint64_t* out) {
+  if (!srs || !out || basis < 0 || basis > 1) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_get: bad argument");
+  if (!srs->table[basis]) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_get: basis %d was not uploaded", basis);
+  ZK_HIP(ctx, hipMemcpyAsync(out, srs->table[basis], srs->n * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AMDZK_OK;
+}
+
 void zk_srs_free(amdzk_ctx*, amdzk_srs* s) {
   if (!s) return;
   for (int b = 0; b < 2; b++)

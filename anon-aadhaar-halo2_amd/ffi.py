@@ -46,6 +46,9 @@ def lib():
         "amdzk_srs_write": (i32, [vp, vp, vp, vp, vp, sz]),
         "amdzk_srs_read": (i32, [vp, vp, sz, C.POINTER(vp), vp, vp]),
         "amdzk_srs_free": (None, [vp, vp]),
+        "amdzk_srs_downsize": (i32, [vp, vp, u32, C.POINTER(vp)]),
+        "amdzk_srs_get": (i32, [vp, vp, i32, vp]),
+        "amdzk_g_to_lagrange": (i32, [vp, vp, u32, vp]),
         "amdzk_msm_g1": (i32, [vp, vp, i32, vp, sz, vp]),
         "amdzk_msm_g1_batch": (i32, [vp, vp, i32, C.POINTER(vp), sz, sz, vp]),
         "amdzk_msm_g1_dev": (i32, [vp, vp, i32, vp, sz, sz, sz, vp]),

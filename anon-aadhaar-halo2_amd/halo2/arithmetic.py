@@ -53,3 +53,13 @@ def best_multiexp_dev(ctx, srs, basis, dbuf, ncols, length, col_stride=None):
     out = np.zeros((ncols, 12), dtype=np.uint64)
     ctx._chk(ctx.L.amdzk_msm_g1_dev(ctx.h, srs, basis, dbuf.ptr, ncols, length, col_stride, _ptr(out)))
     return out
+
+
+def g_to_lagrange(ctx, g, k):
+    """arithmetic::g_to_lagrange(g_projective, k): (n, 8) uint64 affine points in the monomial basis ->
+    the Lagrange-basis points (1/n)·FFT_{omega^-1}(g), affine."""
+    g = np.ascontiguousarray(g, dtype=np.uint64)
+    assert g.shape == (1 << k, 8)
+    out = np.zeros_like(g)
+    ctx._chk(ctx.L.amdzk_g_to_lagrange(ctx.h, _ptr(g), k, _ptr(out)))
+    return out

@@ -63,6 +63,27 @@ class ParamsKZG:
         self.h = h
         return self, bytes(g2), bytes(s_g2)
 
+    def downsize(self, k):
+        """ParamsKZG::downsize(k): shrink in place to 2^k — g truncated, g_lagrange recomputed on the
+        device with g_to_lagrange."""
+        h = C.c_void_p()
+        self.ctx._chk(self.ctx.L.amdzk_srs_downsize(self.ctx.h, self.h, k, C.byref(h)))
+        self.ctx.L.amdzk_srs_free(self.ctx.h, self.h)
+        self.h, self.k, self.n = h, k, 1 << k
+        self._g = None if self._g is None else np.ascontiguousarray(self._g[: self.n])
+        self._gl = None if self._gl is None else self.get_g_lagrange()
+
+    def get_g(self):
+        """ParamsKZG::get_g(): (n, 8) uint64 affine points."""
+        out = np.zeros((self.n, 8), np.uint64)
+        self.ctx._chk(self.ctx.L.amdzk_srs_get(self.ctx.h, self.h, BASIS_G, _ptr(out)))
+        return out
+
+    def get_g_lagrange(self):
+        out = np.zeros((self.n, 8), np.uint64)
+        self.ctx._chk(self.ctx.L.amdzk_srs_get(self.ctx.h, self.h, BASIS_G_LAGRANGE, _ptr(out)))
+        return out
+
     def commit(self, poly_coeff):
         """ParamsKZG::commit(poly, _blind): MSM with g[..len] (the blind is ignored for KZG)."""
         return arithmetic.best_multiexp(self.ctx, self.h, BASIS_G, poly_coeff)

@@ -92,7 +92,17 @@ int amdzk_srs_write(amdzk_ctx* ctx, const amdzk_srs* srs, const uint8_t g2[64], 
                     uint8_t* out, size_t cap);
 int amdzk_srs_read(amdzk_ctx* ctx, const uint8_t* data, size_t len, amdzk_srs** out,
                    uint8_t g2_out[64], uint8_t s_g2_out[64]);
+/* ParamsKZG::downsize(new_k) [UP]: params for a smaller domain from the same trapdoor: g[..2^new_k]
+ * is kept and g_lagrange recomputed with arithmetic::g_to_lagrange (below). Upstream shrinks in place;
+ * here a new handle is returned and `srs` stays valid (free both). Fails if new_k > k. */
+int amdzk_srs_downsize(amdzk_ctx* ctx, const amdzk_srs* srs, uint32_t new_k, amdzk_srs** out);
+/* ParamsKZG::get_g() [UP] (basis 0) / the g_lagrange vector (basis 1): 2^k G1Affine to the host. */
+int amdzk_srs_get(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, uint64_t* out);
 void amdzk_srs_free(amdzk_ctx* ctx, amdzk_srs* srs);
+/* arithmetic::g_to_lagrange(g_projective, k) [UP]: g_lagrange = (1/n) FFT_{omega^-1}(g) over G1 — radix-2
+ * butterflies whose twiddle products are scalar multiplications — normalised to affine.
+ * g, g_lagrange_out: 2^k G1Affine on the host. */
+int amdzk_g_to_lagrange(amdzk_ctx* ctx, const uint64_t* g, uint32_t k, uint64_t* g_lagrange_out);
 
 /* ---- MSM: replaces arithmetic::best_multiexp(coeffs, bases) as called from
  * ParamsKZG::commit / commit_lagrange [UP].

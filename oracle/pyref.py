@@ -153,6 +153,32 @@ def best_fft(a, w, log_n):
     return a
 
 
+def g_to_lagrange(g, k):
+    """arithmetic.rs g_to_lagrange [UP]: best_fft over the group with omega^-1 (same bit-reversal + DIT
+    network as best_fft above, the twiddle product being a scalar multiplication), then every point
+    times 1/n. g: n affine points (None = identity); returns n affine points."""
+    n = 1 << k
+    w = pow(omega(k), -1, R)
+    a = list(g)
+    for i in range(n):
+        ri = int(format(i, "0%db" % k)[::-1], 2) if k else 0
+        if i < ri:
+            a[i], a[ri] = a[ri], a[i]
+    tw = [pow(w, i, R) for i in range(n // 2)]
+    chunk, tchunk = 2, n // 2
+    for _ in range(k):
+        for base in range(0, n, chunk):
+            for i in range(chunk // 2):
+                t = g1_mul(a[base + i + chunk // 2], tw[i * tchunk])
+                u = a[base + i]
+                a[base + i] = g1_add(u, t)
+                a[base + i + chunk // 2] = g1_add(u, g1_neg(t))
+        chunk *= 2
+        tchunk //= 2
+    n_inv = pow(n, -1, R)
+    return [g1_mul(p, n_inv) for p in a]
+
+
 class EvaluationDomain:
     """poly/domain.rs EvaluationDomain [UP]: new(j, k), lagrange_to_coeff, coeff_to_extended,
     extended_to_coeff, divide_by_vanishing_poly, rotate_extended, l_i_range."""

@@ -128,6 +128,51 @@ def test_srs_setup_on_device_matches_oracle(ctx, pkg, oracle):
     params.free()
 
 
+def test_g_to_lagrange_matches_oracle(ctx, pkg, oracle):
+    """arithmetic::g_to_lagrange on the device (FFT over G1): against the pure-Python restatement on
+    small domains, including points at infinity and repeated points, and against the closed-form
+    Lagrange basis of a tau-powers SRS at k = 10."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import pyref as P
+
+    tau = 0x1234567890ABCDEF1234567
+    for k in (0, 1, 3, 5):
+        g, _ = zu.test_srs(oracle, k, tau)
+        if k == 3:
+            g[2] = 0          # identity
+            g[5] = g[4]       # u == v -> u - v = identity, u + v = doubling
+            x6, y6 = zu.point_to_ints(g[6])
+            g[7] = zu.point_from_ints((x6, (-y6) % P.Q))  # v == -u
+        got = pkg.arithmetic.g_to_lagrange(ctx, g, k)
+        want = P.g_to_lagrange([zu.point_to_ints(p) for p in g], k)
+        assert [zu.point_to_ints(p) for p in got] == want, k
+    g, gl = zu.test_srs(oracle, 10, tau)
+    assert np.array_equal(pkg.arithmetic.g_to_lagrange(ctx, g, 10), gl)
+
+
+def test_params_downsize(ctx, pkg, oracle):
+    """ParamsKZG::downsize: g truncated, g_lagrange recomputed for the smaller domain (equal to a fresh
+    setup at that k with the same trapdoor), commitments agree across bases, growing is refused."""
+    tau = 0x1234567890ABCDEF1234567
+    params = pkg.kzg.ParamsKZG.setup(ctx, 10, zu.fr_from_int(tau), want_host_copy=True)
+    with pytest.raises(pkg.AmdzkError):
+        params.downsize(11)
+    params.downsize(7)
+    g, gl = zu.test_srs(oracle, 7, tau)
+    assert params.k == 7 and params.n == 128
+    assert np.array_equal(params.get_g(), g) and np.array_equal(params.get_g_lagrange(), gl)
+    assert np.array_equal(params._g, g) and np.array_equal(params._gl, gl)
+    p = zu.random_fr(128, seed=5)
+    od = zu.OracleDomain(oracle, 3, 7)
+    a = zu.jac_to_affine_host(oracle, params.commit_lagrange(p))
+    assert np.array_equal(a, zu.jac_to_affine_host(oracle, params.commit(od.lagrange_to_coeff(p))))
+    assert np.array_equal(a, oracle.best_multiexp(p, gl))
+    fresh = pkg.kzg.ParamsKZG.setup(ctx, 7, zu.fr_from_int(tau))
+    assert fresh.write() == params.write()
+    fresh.free(); params.free()
+
+
 def test_msm_k22_full_size_tau_identity(ctx, pkg, oracle):
     """BASELINE config 5 size. With bases g_i = s^i G (device-built SRS), MSM(c, g) must equal
     eval_polynomial(c, s) * G — a size-independent identity checked at n = 2^22 against the oracle's

@@ -73,6 +73,20 @@ def test_g1_and_srs(oracle):
     assert [zu.point_to_ints(p) for p in srs] == [(I(p[0]), I(p[1])) for p in G["srs"]["g"]]
 
 
+def test_g_to_lagrange_against_closed_form(oracle):
+    """pyref.g_to_lagrange (the group FFT of arithmetic.rs [UP]) on g_i = tau^i G gives L_i(tau) G, the
+    closed-form Lagrange basis the C oracle builds from scalars (zkutil.test_srs)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import pyref as P
+
+    tau = 0x1234567890ABCDEF1234567
+    for k in (0, 1, 2, 4):
+        g, gl = zu.test_srs(oracle, k, tau)
+        got = P.g_to_lagrange([zu.point_to_ints(p) for p in g], k)
+        assert got == [zu.point_to_ints(p) for p in gl]
+
+
 def test_msm_vectors(oracle):
     srs = np.array([zu.point_from_ints((I(p[0]), I(p[1]))) for p in G["srs"]["g"]], dtype=np.uint64)
     for v in G["msm"]:
