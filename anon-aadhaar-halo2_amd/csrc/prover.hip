@@ -987,6 +987,18 @@ size_t amdzk_proof_random_count(const amdzk_pk* pk) {
          pk->n + 1 + pk->qdeg;
 }
 
+// Length of the proof create_proof writes for this key: commitments — advice, 2 per lookup (A', S'), one per
+// permutation set, one per lookup product, the random polynomial, the h pieces, SHPLONK's two — then the
+// evaluations: advice and fixed queries, the random polynomial, sigma columns, 3 per permutation set but 2
+// for the last, 5 per lookup.
+size_t amdzk_proof_size(const amdzk_pk* pk, int transcript_kind) {
+  if (!pk) return 0;
+  const size_t points = (size_t)pk->A + 2 * (size_t)pk->L + pk->nsets + pk->L + 1 + pk->qdeg + 2;
+  const size_t scalars = pk->advice_queries.size() + pk->fixed_queries.size() + 1 + pk->S + (pk->nsets ? 3 * (size_t)pk->nsets - 1 : 0) +
+                         5 * (size_t)pk->L;
+  return points * (transcript_kind == AMDZK_TRANSCRIPT_KECCAK256_EVM ? 64 : 32) + scalars * 32;
+}
+
 // create_proof with the caller's randomness: `scalars` = amdzk_proof_random_count(pk) Fr elements
 // (Montgomery), drawn by the caller with Fr::random(&mut rng) in order.
 int amdzk_create_proof_scalars(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances, const size_t* instance_lens,

@@ -72,6 +72,7 @@ def lib():
         "amdzk_create_proof": (i32, [vp, vp, C.POINTER(vp), C.POINTER(sz), vp, sz, C.c_uint64, vp, sz, C.POINTER(sz)]),
         "amdzk_create_proof_ex": (i32, [vp, vp, C.POINTER(vp), C.POINTER(sz), vp, sz, C.c_uint64, i32, vp, sz, C.POINTER(sz)]),
         "amdzk_proof_random_count": (sz, [vp]),
+        "amdzk_proof_size": (sz, [vp, i32]),
         "amdzk_create_proof_scalars": (i32, [vp, vp, C.POINTER(vp), C.POINTER(sz), vp, sz, vp, sz, i32, vp, sz, C.POINTER(sz)]),
         "amdzk_timer_start": (i32, [vp]),
         "amdzk_timer_stop": (i32, [vp, C.POINTER(C.c_float)]),

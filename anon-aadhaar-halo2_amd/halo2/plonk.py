@@ -372,6 +372,10 @@ def create_proof(ctx, pk, instances, d_advice, seed, advice_stride=None, transcr
     return bytes(buf[: need.value])
 
 
+def proof_size(ctx, pk, transcript=TRANSCRIPT_BLAKE2B):
+    return int(ctx.L.amdzk_proof_size(pk.h, transcript))
+
+
 def proof_random_count(ctx, pk):
     return int(ctx.L.amdzk_proof_random_count(pk.h))
 

@@ -213,6 +213,8 @@ int amdzk_create_proof_ex(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* i
                           const size_t* instance_lens, const void* d_advice, size_t advice_stride,
                           uint64_t rng_seed, int transcript_kind, uint8_t* proof_out,
                           size_t proof_cap, size_t* proof_len);
+/* Exact byte length of the proof for this key and transcript (a function of the circuit shape only). */
+size_t amdzk_proof_size(const amdzk_pk* pk, int transcript_kind);
 /* For callers whose `R: RngCore` is not ChaCha20Rng::seed_from_u64: draw
  * amdzk_proof_random_count(pk) scalars with Fr::random(&mut rng) and pass them (Montgomery Fr, in
  * draw order); the prover consumes them exactly where upstream's create_proof draws. */

@@ -25,12 +25,14 @@ class Circuit:
         self.advice = [[0] * self.n for _ in range(cs.num_advice)]
         self.instances = [[] for _ in range(cs.num_instance)]
         self.assembly = None
+        self.copies = []  # (perm column, row, perm column, row) in the order they were made
 
     def perm_index(self, col):
         return self.cs.permutation_columns.index(col)
 
     def copy(self, c1, r1, c2, r2):
-        self.assembly.copy(self.perm_index(c1), r1, self.perm_index(c2), r2)
+        self.copies.append((self.perm_index(c1), r1, self.perm_index(c2), r2))
+        self.assembly.copy(*self.copies[-1])
 
     def value(self, col, row):
         if col.kind == 0:

@@ -136,6 +136,9 @@ def test_full_aadhaar_shape_equals_oracle(ctx, pkg, plonk, oracle):
     assert PR.verify_proof(vk_from_device(pk, c), c.instances, proof)
     fpk = PF.FastKey(c.desc, c.fixed, c.assembly.mapping, TAU, 123456789)
     assert proof == PF.create_proof(fpk, c.instances, c.advice, seed=77)
+    evm = plonk.create_proof(ctx, pk, inst, d_adv, seed=78, transcript=plonk.TRANSCRIPT_KECCAK256_EVM)
+    assert PR.verify_proof(vk_from_device(pk, c), c.instances, evm, transcript="evm")
+    assert evm == PF.create_proof(fpk, c.instances, c.advice, seed=78, transcript="evm")
     d_adv.free(); pk.free(); params.free()
 
 
