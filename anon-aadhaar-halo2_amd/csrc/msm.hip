@@ -365,26 +365,40 @@ __device__ __forceinline__ G1X x_mul_small(const G1X& p, uint32_t k, int nbits) 
 }
 
 // out[col] = sum_r r*cols[r] + sum_g (64g+1)*rows[g]
-__global__ __launch_bounds__(512) void msm_fold_kernel(const G1X* rows, const G1X* cols, uint32_t nb,
-                                                        G1X* out) {
-  __shared__ G1X part[9];
+//          = sum_r r*cols[r] + 64 * (sum_g g*rows[g]) + sum_g rows[g].
+// Three independent reductions on separate wavefronts (W = ceil(G/64) waves for each row sum, one for
+// the columns), so the dependent chain is a 6..9-bit double-and-add, one shuffle tree, six doublings
+// and a handful of additions — the kernel is pure latency (one workgroup per column).
+__global__ __launch_bounds__(1024) void msm_fold_kernel(const G1X* rows, const G1X* cols, uint32_t nb, G1X* out, int split) {
+  __shared__ G1X part[17];
   const uint32_t col = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const uint32_t G = nb >> 6;
-  G1X v = G1X::inf();
-  if (t < G) v = x_mul_small(ld_x(rows + (size_t)col * G + t), 64 * t + 1, 6 + (32 - __clz(G > 1 ? G - 1 : 1)));
-  G1X s = wave_sum(v);
-  if (lane == 0) part[wv] = s;
-  if (wv == 0) {
-    G1X c = x_mul_small(ld_x(cols + (size_t)col * 64 + lane), lane, 6);
-    G1X cs = wave_sum(c);
-    if (lane == 0) part[8] = cs;
+  const uint32_t G = nb >> 6, W = (G + 63) >> 6;
+  const int gbits = 32 - __clz(G > 1 ? G - 1 : 1);
+  if (wv < W) {  // sum_g g*rows[g]  (and, when not split, sum_g rows[g] as well)
+    const uint32_t g = wv * 64 + lane;
+    G1X v = g < G ? ld_x(rows + (size_t)col * G + g) : G1X::inf();
+    G1X s = wave_sum(x_mul_small(v, g, gbits));
+    if (lane == 0) part[wv] = s;
+    if (!split) {
+      G1X u = wave_sum(v);
+      if (lane == 0) part[8 + wv] = u;
+    }
+  } else if (split && wv < 2 * W) {  // sum_g rows[g]
+    const uint32_t g = (wv - W) * 64 + lane;
+    G1X u = wave_sum(g < G ? ld_x(rows + (size_t)col * G + g) : G1X::inf());
+    if (lane == 0) part[8 + wv - W] = u;
+  } else {  // sum_r r*cols[r]
+    G1X c = wave_sum(x_mul_small(ld_x(cols + (size_t)col * 64 + lane), lane, 6));
+    if (lane == 0) part[16] = c;
   }
   __syncthreads();
   if (t == 0) {
-    G1X acc = part[8];
-    const uint32_t nw = blockDim.x >> 6;
-    for (uint32_t i = 0; i < nw; i++) acc = x_add(acc, part[i]);
-    st_x(out + col, acc);
+    G1X acc = part[0];
+    for (uint32_t i = 1; i < W; i++) acc = x_add(acc, part[i]);
+#pragma unroll 1
+    for (int i = 0; i < 6; i++) acc = x_dbl(acc);
+    for (uint32_t i = 0; i < W; i++) acc = x_add(acc, part[8 + i]);
+    st_x(out + col, x_add(acc, part[16]));
   }
 }
 
@@ -913,8 +927,10 @@ int zk_msm_dev_xyzz(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const Fr* d
   ZK_LAUNCH(ctx, "msm_accum_final", msm_accum_final_kernel, dim3(nb / 64, (unsigned)ncols), dim3(64), 0, off[NLEV], nb, list[NLEV], cap[NLEV],
             dense);
   ZK_LAUNCH(ctx, "msm_rowcol", msm_rowcol_kernel, dim3((unsigned)(G + 64), (unsigned)ncols), dim3(64), 0, dense, nb, rows, cols);
-  const unsigned fold_threads = G > 64 ? (unsigned)G : 64u;
-  ZK_LAUNCH(ctx, "msm_fold", msm_fold_kernel, dim3((unsigned)ncols), dim3(fold_threads), 0, rows, cols, nb, outp);
+  const unsigned fold_w = (unsigned)((G + 63) / 64);  // <= 8
+  const int fold_split = 2 * fold_w + 1 <= 16;
+  ZK_LAUNCH(ctx, "msm_fold", msm_fold_kernel, dim3((unsigned)ncols), dim3(64 * ((fold_split ? 2 : 1) * fold_w + 1)), 0, rows, cols, nb, outp,
+            fold_split);
   *d_out = outp;
   return AMDZK_OK;
 }
