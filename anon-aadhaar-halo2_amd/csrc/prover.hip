@@ -990,10 +990,30 @@ size_t amdzk_proof_random_count(const amdzk_pk* pk) {
 // Length of the proof create_proof writes for this key: commitments — advice, 2 per lookup (A', S'), one per
 // permutation set, one per lookup product, the random polynomial, the h pieces, SHPLONK's two — then the
 // evaluations: advice and fixed queries, the random polynomial, sigma columns, 3 per permutation set but 2
-// for the last, 5 per lookup.
-size_t amdzk_proof_size(const amdzk_pk* pk, int transcript_kind) {
+// for the last, 5 per lookup. With AMDZK_MULTIOPEN_GWC the two SHPLONK points become one per opening point.
+// Distinct evaluation points of the proof's queries = distinct rotations (omega^r x are pairwise different
+// for the |r| << n that occur): what ProverGWC writes one witness commitment for.
+static size_t opening_point_count(const amdzk_pk* pk) {
+  std::vector<int> rots = {0};  // sigma columns, h(X), the random polynomial
+  auto note = [&](int r) {
+    if (std::find(rots.begin(), rots.end(), r) == rots.end()) rots.push_back(r);
+  };
+  for (auto& q : pk->advice_queries) note(q.second);
+  for (auto& q : pk->fixed_queries) note(q.second);
+  if (pk->nsets) note(1);
+  if (pk->nsets > 1) note(-(int)(pk->bf + 1));
+  if (pk->L) {
+    note(1);
+    note(-1);
+  }
+  return rots.size();
+}
+
+size_t amdzk_proof_size(const amdzk_pk* pk, int format) {
   if (!pk) return 0;
-  const size_t points = (size_t)pk->A + 2 * (size_t)pk->L + pk->nsets + pk->L + 1 + pk->qdeg + 2;
+  const int transcript_kind = format & 0xff;
+  const size_t openings = (format & AMDZK_MULTIOPEN_GWC) ? opening_point_count(pk) : 2;
+  const size_t points = (size_t)pk->A + 2 * (size_t)pk->L + pk->nsets + pk->L + 1 + pk->qdeg + openings;
   const size_t scalars = pk->advice_queries.size() + pk->fixed_queries.size() + 1 + pk->S + (pk->nsets ? 3 * (size_t)pk->nsets - 1 : 0) +
                          5 * (size_t)pk->L;
   return points * (transcript_kind == AMDZK_TRANSCRIPT_KECCAK256_EVM ? 64 : 32) + scalars * 32;
@@ -1039,6 +1059,8 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
   const uint32_t F = pk->F, A = pk->A, I = pk->I, S = pk->S, L = pk->L, ns = pk->nsets, bf = pk->bf;
   const size_t usable = n - (bf + 1);
   if (advice_stride < n) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: advice stride < n");
+  const bool use_gwc = (transcript_kind & AMDZK_MULTIOPEN_GWC) != 0;
+  transcript_kind &= ~AMDZK_MULTIOPEN_GWC;
   zkhost::Blake2bWrite t_blake;
   zkhost::Keccak256Write t_keccak;
   if (transcript_kind != AMDZK_TRANSCRIPT_BLAKE2B && transcript_kind != AMDZK_TRANSCRIPT_KECCAK256_EVM)
@@ -1317,7 +1339,64 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
   addpq(pk->hpoly, 0);
   addpq(pk->rnd, 0);
 
-  // 9. SHPLONK (multiopen/shplonk/prover.rs [UP])
+  // 9a. GWC (multiopen/gwc/prover.rs [UP]): v <- transcript; queries grouped by point in first-seen order;
+  // per point z:  W_z = (sum_j v^j p_j - sum_j v^j p_j(z)) / (X - z), committed and written in that order.
+  if (use_gwc) {
+    struct PS {
+      std::array<uint64_t, 4> key;
+      Fr z;
+      std::vector<const Fr*> polys;
+      std::vector<Fr> evals;
+    };
+    std::vector<PS> psets;
+    for (auto& q : queries) {
+      const std::array<uint64_t, 4> key = canon(q.point);
+      PS* hit = nullptr;
+      for (auto& ps : psets)
+        if (ps.key == key) hit = &ps;
+      if (!hit) {
+        psets.push_back(PS{key, q.point, {}, {}});
+        hit = &psets.back();
+      }
+      hit->polys.push_back(q.poly);
+      hit->evals.push_back(q.eval);
+    }
+    const size_t np = psets.size();
+    if (np > 16) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "create_proof: more than 16 opening points");
+    Fr v = T.squeeze_challenge();
+    trace_fr("gwc_v", v);
+    for (size_t i = 0; i < np; i++) {
+      const size_t m = psets[i].polys.size();
+      if (m > pk->ptrs_cap || m + 1 > pk->small_cap) ZK_FAIL(ctx, AMDZK_E_NOMEM, "create_proof: opening set too large");
+      std::vector<Fr> cf(m);
+      Fr cur = Fr::one(), eb = Fr::zero();
+      for (size_t j = 0; j < m; j++) {
+        cf[j] = cur;
+        eb = add(eb, mul(cur, psets[i].evals[j]));
+        cur = mul(cur, v);
+      }
+      std::vector<Fr> low = {eb};
+      Fr* Wi = pk->sets_N + i * n;
+      ZK_TRY(h2d_staged(ctx, pk, pk->ptrs, psets[i].polys.data(), m * sizeof(Fr*)));
+      ZK_TRY(upload_small(cf, 0));
+      ZK_TRY(upload_small(low, m));
+      ZK_TRY(zk_lincomb(ctx, (const Fr* const*)pk->ptrs, pk->small, (uint32_t)m, Wi, n, false));
+      ZK_TRY(zk_sub_low(ctx, Wi, pk->small + m, 1));
+    }
+    std::vector<Fr*> pp(np);
+    std::vector<Fr> roots(np);
+    for (size_t i = 0; i < np; i++) {
+      pp[i] = pk->sets_N + i * n;
+      roots[i] = psets[i].z;
+    }
+    ZK_TRY(h2d_staged(ctx, pk, pk->ptrs, pp.data(), np * sizeof(Fr*)));
+    ZK_TRY(upload_small(roots, 0));
+    ZK_TRY(zk_kate_div(ctx, (Fr* const*)pk->ptrs, pk->small, np, (uint32_t)n));
+    std::vector<G1Affine> cm;
+    ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G, pk->sets_N, np, cm));
+    ZK_TRY(write_points(cm, "gwc_w"));
+  } else
+  // 9b. SHPLONK (multiopen/shplonk/prover.rs [UP])
   {
     // construct_intermediate_sets
     struct CR {
@@ -1485,7 +1564,7 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G, lx, 1, cm));
     ZK_TRY(write_points(cm, "shplonk_h2"));
   }
-  tick("shplonk");
+  tick("multiopen");
   if (rng.exhausted) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: ran out of caller-supplied random scalars");
   *proof_len = T.proof.size();
   if (proof_out) {

@@ -354,6 +354,7 @@ class ProvingKey:
 
 
 TRANSCRIPT_BLAKE2B, TRANSCRIPT_KECCAK256_EVM = 0, 1
+MULTIOPEN_GWC = 0x100  # OR into `transcript`: poly::kzg::multiopen::ProverGWC instead of ProverSHPLONK
 
 
 def create_proof(ctx, pk, instances, d_advice, seed, advice_stride=None, transcript=TRANSCRIPT_BLAKE2B):

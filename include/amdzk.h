@@ -161,7 +161,8 @@ int amdzk_divide_by_vanishing_dev(amdzk_ctx* ctx, const amdzk_domain* dom, void*
                                   size_t col_stride);
 
 /* ---- create_proof: replaces plonk::{keygen_pk, create_proof} [UP] for
- * KZGCommitmentScheme<Bn256> + ProverSHPLONK + Blake2bWrite/Challenge255, one circuit instance,
+ * KZGCommitmentScheme<Bn256> + ProverSHPLONK (or ProverGWC, AMDZK_MULTIOPEN_GWC) + Blake2bWrite/Challenge255
+ * (or the EVM transcript), one circuit instance,
  * phase-0 advice. The circuit arrives as plain data: what ConstraintSystem holds after
  * Circuit::configure (/root/reference/src/lib.rs:295-326 etc.) and selector compression.
  *
@@ -209,11 +210,16 @@ int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* inst
  * 32-byte big-endian scalars, contract.sol:77-112). */
 #define AMDZK_TRANSCRIPT_BLAKE2B 0
 #define AMDZK_TRANSCRIPT_KECCAK256_EVM 1
+/* OR into `transcript_kind` to open with poly::kzg::multiopen::ProverGWC instead of ProverSHPLONK
+ * (SURVEY.md §8(a) row a12): one witness commitment W_z = (sum_j v^j p_j - sum_j v^j p_j(z)) / (X - z) per
+ * distinct evaluation point z, points in first-seen query order. */
+#define AMDZK_MULTIOPEN_GWC 0x100
 int amdzk_create_proof_ex(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances,
                           const size_t* instance_lens, const void* d_advice, size_t advice_stride,
                           uint64_t rng_seed, int transcript_kind, uint8_t* proof_out,
                           size_t proof_cap, size_t* proof_len);
-/* Exact byte length of the proof for this key and transcript (a function of the circuit shape only). */
+/* Exact byte length of the proof for this key, transcript and multiopen scheme (transcript_kind as for
+ * amdzk_create_proof_ex, including AMDZK_MULTIOPEN_GWC); a function of the circuit shape only. */
 size_t amdzk_proof_size(const amdzk_pk* pk, int transcript_kind);
 /* For callers whose `R: RngCore` is not ChaCha20Rng::seed_from_u64: draw
  * amdzk_proof_random_count(pk) scalars with Fr::random(&mut rng) and pass them (Montgomery Fr, in

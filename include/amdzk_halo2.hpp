@@ -608,12 +608,15 @@ class ProvingKey {
 };
 
 enum class Transcript : int { Blake2b = AMDZK_TRANSCRIPT_BLAKE2B, Keccak256Evm = AMDZK_TRANSCRIPT_KECCAK256_EVM };
+// The `P: Prover` type parameter of create_proof: poly::kzg::multiopen::{ProverSHPLONK, ProverGWC}.
+enum class Multiopen : int { Shplonk = 0, Gwc = AMDZK_MULTIOPEN_GWC };
 
 // plonk::create_proof(params, pk, &[circuit], &[instances], ChaCha20Rng::seed_from_u64(seed), transcript) for
 // one circuit. `d_advice`: the witness columns resident on the GPU (column c at d_advice + c*stride Fr).
 inline std::vector<uint8_t> create_proof(const Context& ctx, const ProvingKey& pk, const std::vector<std::vector<Fr>>& instances,
                                          const void* d_advice, size_t advice_stride, uint64_t rng_seed,
-                                         Transcript transcript = Transcript::Blake2b) {
+                                         Transcript transcript = Transcript::Blake2b, Multiopen multiopen = Multiopen::Shplonk) {
+  const int format = (int)transcript | (int)multiopen;
   std::vector<const uint64_t*> ptrs(std::max<size_t>(1, instances.size()), nullptr);
   std::vector<size_t> lens(std::max<size_t>(1, instances.size()), 0);
   for (size_t i = 0; i < instances.size(); i++) {
@@ -621,8 +624,8 @@ inline std::vector<uint8_t> create_proof(const Context& ctx, const ProvingKey& p
     lens[i] = instances[i].size();
   }
   size_t need = 0;
-  std::vector<uint8_t> proof(amdzk_proof_size(pk.handle(), (int)transcript));
-  ctx.check(amdzk_create_proof_ex(ctx.get(), pk.handle(), ptrs.data(), lens.data(), d_advice, advice_stride, rng_seed, (int)transcript,
+  std::vector<uint8_t> proof(amdzk_proof_size(pk.handle(), format));
+  ctx.check(amdzk_create_proof_ex(ctx.get(), pk.handle(), ptrs.data(), lens.data(), d_advice, advice_stride, rng_seed, format,
                                   proof.data(), proof.size(), &need));
   proof.resize(need);
   return proof;
@@ -632,7 +635,7 @@ inline std::vector<uint8_t> create_proof(const Context& ctx, const ProvingKey& p
 // advice columns (padded with zeros to 2^k rows), proves, frees.
 inline std::vector<uint8_t> create_proof(const Context& ctx, const ProvingKey& pk, const std::vector<std::vector<Fr>>& instances,
                                          const std::vector<std::vector<Fr>>& advice, uint64_t rng_seed,
-                                         Transcript transcript = Transcript::Blake2b) {
+                                         Transcript transcript = Transcript::Blake2b, Multiopen multiopen = Multiopen::Shplonk) {
   const size_t n = (size_t)1 << pk.k();
   if (advice.size() != pk.num_advice()) throw Error(AMDZK_E_INVALID, "create_proof: advice column count");
   std::vector<Fr> flat(std::max<size_t>(1, advice.size()) * n, Fr::zero());
@@ -645,7 +648,7 @@ inline std::vector<uint8_t> create_proof(const Context& ctx, const ProvingKey& p
   std::vector<uint8_t> proof;
   try {
     ctx.check(amdzk_dev_upload(ctx.get(), d, flat.data(), flat.size() * sizeof(Fr)));
-    proof = create_proof(ctx, pk, instances, d, n, rng_seed, transcript);
+    proof = create_proof(ctx, pk, instances, d, n, rng_seed, transcript, multiopen);
   } catch (...) {
     amdzk_dev_free(ctx.get(), d);
     throw;

@@ -417,7 +417,7 @@ def poly_eval_fn(polys_by_kind, d):
     return get_at
 
 
-def create_proof(pk, instances, advice_values, seed, trace=None, transcript="blake2b"):
+def create_proof(pk, instances, advice_values, seed, trace=None, transcript="blake2b", multiopen="shplonk"):
     """plonk::prover::create_proof for one circuit instance, KZG + SHPLONK + Blake2b, phase 0 only.
     instances[c] = list of public inputs of instance column c; advice_values[c] = n ints (rows past
     the usable range are overwritten by blinding). Returns the proof bytes."""
@@ -605,7 +605,10 @@ def create_proof(pk, instances, advice_values, seed, trace=None, transcript="bla
         Qy(p, 0)
     Qy(h_poly, 0)
     Qy(random_poly, 0)
-    shplonk_prove(queries, T, tau, n, tr)
+    if multiopen == "gwc":
+        gwc_prove(queries, T, tau, n, tr)
+    else:
+        shplonk_prove(queries, T, tau, n, tr)
     return bytes(T.proof)
 
 
@@ -723,6 +726,42 @@ def shplonk_prove(queries, T, tau, n, tr):
     tr("shplonk_h2", c2)
 
 
+def gwc_point_sets(queries):
+    """multiopen::gwc::construct_intermediate_sets [UP]: group the queries by evaluation point, points in
+    first-seen order, the queries of one point in their original order. queries = [(item, point)]."""
+    sets = []
+    for item, pt in queries:
+        for s in sets:
+            if s[0] == pt:
+                s[1].append(item)
+                break
+        else:
+            sets.append((pt, [item]))
+    return sets
+
+
+def gwc_prove(queries, T, tau, n, tr):
+    """multiopen::gwc::ProverGWC::create_proof [UP]: v <- transcript; per point z: the queries' polynomials
+    and evaluations are combined with 1, v, v^2, ...; W_z = (sum v^j p_j - sum v^j p_j(z)) / (X - z) is
+    committed and written."""
+    v = T.squeeze_challenge()
+    tr("gwc_v", v)
+    for z, polys in gwc_point_sets(queries):
+        acc = [0] * n
+        ev = 0
+        vp = 1
+        for poly in polys:
+            for i in range(n):
+                acc[i] = (acc[i] + vp * poly[i]) % R
+            ev = (ev + vp * P.eval_polynomial(poly, z)) % R
+            vp = vp * v % R
+        acc[0] = (acc[0] - ev) % R
+        w = P.kate_division(acc, z)
+        c = commit_tau(w + [0] * (n - len(w)), tau)
+        T.write_point(c)
+        tr("gwc_w", c)
+
+
 # ------------------------------------------------------------------------------------ verifier
 class VerifyingKey:
     """What a verifier holds: the constraint-system description, the commitments of the fixed and
@@ -747,7 +786,7 @@ def lagrange_basis_at(d, n, rows, x):
     return out
 
 
-def verify_proof(pk, instances, proof, transcript="blake2b"):
+def verify_proof(pk, instances, proof, transcript="blake2b", multiopen="shplonk"):
     """Checks: transcript re-derivation, the vanishing identity at x, and the SHPLONK opening equation
     (in G1, with the known tau standing in for the pairing). Raises AssertionError on failure."""
     desc, d, n, tau = pk.desc, pk.domain, pk.n, pk.tau
@@ -843,6 +882,28 @@ def verify_proof(pk, instances, proof, transcript="blake2b"):
         Qv(("s", i), pk.permutation_commitments[i], 0, sig_e[i])
     Qv(("h",), h_commit, 0, expected_h)
     Qv(("r",), rand_c, 0, rand_e)
+    if multiopen == "gwc":
+        # multiopen::gwc::VerifierGWC [UP]: e(sum u^i W_i, [tau]_2) = e(sum u^i z_i W_i + C - e*G, [1]_2), checked
+        # in G1 with the known tau. C / e fold each point's commitments / evaluations with powers of v.
+        v = T.squeeze_challenge()
+        sets = gwc_point_sets([((com, e), pt) for _, com, pt, e in queries])
+        ws = [T.read_point() for _ in sets]
+        u = T.squeeze_challenge()
+        assert T.pos == len(T.data), "trailing bytes in proof"
+        lhs = rhs = None
+        up = 1
+        for (z, items), w in zip(sets, ws):
+            cb, eb, vp = None, 0, 1
+            for com, e in items:
+                cb = P.g1_add(cb, P.g1_mul(com, vp))
+                eb = (eb + vp * e) % R
+                vp = vp * v % R
+            term = P.g1_add(cb, P.g1_neg(P.g1_mul(P.G1_GEN, eb)))
+            rhs = P.g1_add(rhs, P.g1_mul(P.g1_add(term, P.g1_mul(w, z)), up))
+            lhs = P.g1_add(lhs, P.g1_mul(w, up * tau % R))
+            up = up * u % R
+        assert lhs == rhs, "GWC opening equation does not hold"
+        return True
     # SHPLONK
     coms = {k_: c for k_, c, _, _ in queries}
     evmap = {(k_, pt): e for k_, _, pt, e in queries}

@@ -1,7 +1,7 @@
 // Drives include/amdzk_halo2.hpp the way a compiled host (the reference's Rust, through its FFI) would:
 // circuits are configured in C++ against the mirrored ConstraintSystem, then
 //   describe <circuit> <k>                      print the flattened C-ABI arrays (no GPU call)
-//   prove <circuit> <k> <witness> <seed> <blake2b|evm> <tau hex> <transcript_repr hex>
+//   prove <circuit> <k> <witness> <seed> <blake2b|evm>[+gwc] <tau hex> <transcript_repr hex>
 //                                               keygen + create_proof on the GPU, print the proof as hex
 // Circuit configurations mirror tests/circuits.py (and through it /root/reference/src/signal.rs:27-49,
 // src/conditional_secrets.rs:81-187, src/timestamp.rs:58-68, src/lib.rs:295-326); the witness file
@@ -230,11 +230,13 @@ static int prove(int argc, char** argv) {
     }
   }
   const uint64_t seed = std::strtoull(argv[5], nullptr, 10);
-  const Transcript tr = std::string(argv[6]) == "evm" ? Transcript::Keccak256Evm : Transcript::Blake2b;
+  const std::string fmt = argv[6];
+  const Transcript tr = fmt.rfind("evm", 0) == 0 ? Transcript::Keccak256Evm : Transcript::Blake2b;
+  const Multiopen mo = fmt.find("+gwc") != std::string::npos ? Multiopen::Gwc : Multiopen::Shplonk;
   Context ctx(0);
   ParamsKZG params = ParamsKZG::setup(ctx, k, Fr::from_hex(argv[7]));
   ProvingKey pk(ctx, params, cs, fixed, assembly, Fr::from_hex(argv[8]));
-  std::vector<uint8_t> proof = create_proof(ctx, pk, instances, advice, seed, tr);
+  std::vector<uint8_t> proof = create_proof(ctx, pk, instances, advice, seed, tr, mo);
   std::cout << "proof ";
   for (uint8_t b : proof) std::printf("%02x", b);
   std::cout << '\n';

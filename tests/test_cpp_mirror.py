@@ -94,9 +94,10 @@ def test_cpp_driven_proof_equals_oracle(exe, plonk, name, tmp_path):
     wit = str(tmp_path / "witness.txt")
     write_witness(c, wit)
     opk = PR.keygen(c.desc, c.fixed, c.assembly.mapping, TAU, transcript_repr=0xC0FFEE)
-    for tr in ("blake2b", "evm"):
-        out = subprocess.check_output([exe, "prove", name, str(c.k), wit, "17", tr, "%x" % TAU, "%x" % 0xC0FFEE], text=True)
+    for tr, mo in (("blake2b", "shplonk"), ("evm", "shplonk"), ("blake2b", "gwc")):
+        fmt = tr + ("+gwc" if mo == "gwc" else "")
+        out = subprocess.check_output([exe, "prove", name, str(c.k), wit, "17", fmt, "%x" % TAU, "%x" % 0xC0FFEE], text=True)
         proof = bytes.fromhex(out.split("proof ")[1].split()[0])
-        assert proof == PR.create_proof(opk, c.instances, c.advice, seed=17, transcript=tr), (name, tr)
-        assert PR.verify_proof(opk, c.instances, proof, transcript=tr)
+        assert proof == PR.create_proof(opk, c.instances, c.advice, seed=17, transcript=tr, multiopen=mo), (name, fmt)
+        assert PR.verify_proof(opk, c.instances, proof, transcript=tr, multiopen=mo)
         assert "commitments %d %d" % (c.cs.num_fixed, len(c.cs.permutation_columns)) in out

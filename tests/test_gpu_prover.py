@@ -142,6 +142,29 @@ def test_full_aadhaar_shape_equals_oracle(ctx, pkg, plonk, oracle):
     d_adv.free(); pk.free(); params.free()
 
 
+def test_gwc_multiopen_equals_oracle(ctx, pkg, plonk, oracle):
+    """ProverGWC on the device (AMDZK_MULTIOPEN_GWC): bytes equal the oracle's GWC prover on small circuits
+    for both transcripts, amdzk_proof_size predicts the length, and at k = 15 with the composite Aadhaar
+    budget (6 opening points: rotations 0..3, -1, -(bf+1)) the proof verifies with the oracle's GWC verifier."""
+    gwc = plonk.MULTIOPEN_GWC
+    for c in (circuits.square_circuit(plonk, 4, signal=5), circuits.lookup_circuit(plonk, 6, seed=4),
+              circuits.full_aadhaar_shape(plonk, k=7, num_advice=5, num_lookup_advice=2, lookup_bits=5, num_spread=2, spread_bits=3)):
+        params, pk, d_adv, inst = setup(ctx, pkg, plonk, oracle, c)
+        opk = PR.keygen(c.desc, c.fixed, c.assembly.mapping, TAU, transcript_repr=123456789)
+        for kind, name in ((plonk.TRANSCRIPT_BLAKE2B, "blake2b"), (plonk.TRANSCRIPT_KECCAK256_EVM, "evm")):
+            got = plonk.create_proof(ctx, pk, inst, d_adv, seed=12, transcript=kind | gwc)
+            assert got == PR.create_proof(opk, c.instances, c.advice, seed=12, transcript=name, multiopen="gwc")
+            assert len(got) == plonk.proof_size(ctx, pk, kind | gwc)
+            assert len(plonk.create_proof(ctx, pk, inst, d_adv, seed=12, transcript=kind)) == plonk.proof_size(ctx, pk, kind)
+        d_adv.free(); pk.free(); params.free()
+    c = circuits.full_aadhaar_shape(plonk, k=15)
+    params, pk, d_adv, inst = setup(ctx, pkg, plonk, oracle, c)
+    proof = plonk.create_proof(ctx, pk, inst, d_adv, seed=5, transcript=gwc)
+    assert len(proof) == plonk.proof_size(ctx, pk, gwc) == plonk.proof_size(ctx, pk, 0) + 4 * 32
+    assert PR.verify_proof(vk_from_device(pk, c), c.instances, proof, multiopen="gwc")
+    d_adv.free(); pk.free(); params.free()
+
+
 def test_evm_proof_accepted_by_reference_solidity_verifier(ctx, pkg, plonk, oracle):
     """Config 1/3 of BASELINE.json in the form the reference can check: the SquareCircuit
     (/root/reference/src/signal.rs) proved on the MI355X with the Keccak256/EVM transcript equals the

@@ -127,6 +127,30 @@ def test_full_aadhaar_shape_budget_and_oracle_proof(plonk):
         PR.verify_proof(pk, c.instances, PR.create_proof(pk, c.instances, adv, seed=3))
 
 
+def test_gwc_multiopen_oracle_prove_verify(plonk):
+    """multiopen::gwc (SURVEY.md §8(a) row a12, the alternative to SHPLONK): the oracle's GWC prover and
+    verifier agree — one witness commitment per distinct opening point, proofs verify for both
+    transcripts, a flipped byte and an unsatisfied witness are rejected. [UP] restatement, parity unpinned."""
+    for c in (circuits.square_circuit(plonk, 4), circuits.lookup_circuit(plonk, 5, seed=2)):
+        pk = PR.keygen(c.desc, c.fixed, c.assembly.mapping, TAU, transcript_repr=7)
+        rots = {r for _, r in c.desc["advice_queries"]} | {r for _, r in c.desc["fixed_queries"]} | {0, 1}
+        nsets = -(-len(c.desc["permutation_columns"]) // (c.desc["cs_degree"] - 2))
+        rots |= {-(c.desc["blinding_factors"] + 1)} if nsets > 1 else set()
+        rots |= {-1, 1} if c.desc["lookups"] else set()
+        for tr, pt in (("blake2b", 32), ("evm", 64)):
+            proof = PR.create_proof(pk, c.instances, c.advice, seed=3, transcript=tr, multiopen="gwc")
+            assert len(proof) == len(PR.create_proof(pk, c.instances, c.advice, seed=3, transcript=tr)) + (len(rots) - 2) * pt
+            assert PR.verify_proof(pk, c.instances, proof, transcript=tr, multiopen="gwc")
+            bad = bytearray(proof)
+            bad[-1] ^= 1
+            with pytest.raises(AssertionError):
+                PR.verify_proof(pk, c.instances, bytes(bad), transcript=tr, multiopen="gwc")
+        adv = [list(col) for col in c.advice]
+        adv[0][0] += 1
+        with pytest.raises(AssertionError):
+            PR.verify_proof(pk, c.instances, PR.create_proof(pk, c.instances, adv, seed=3, multiopen="gwc"), multiopen="gwc")
+
+
 def test_reference_solidity_verifier_accepts_square_circuit_proof(plonk):
     """The reference's own verifier — solidity_verifier_contract/contract.sol, restated statement by
     statement in oracle/contract_sol.py (pairing replaced by the known-trapdoor check) — accepts the
