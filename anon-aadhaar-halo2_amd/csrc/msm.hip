@@ -29,6 +29,7 @@
 #include <string.h>
 
 #include "common.hpp"
+#include "fp29.cuh"
 
 using namespace bn254;
 
@@ -37,7 +38,12 @@ struct amdzk_srs {
   uint32_t c = 0;        // window bits
   uint32_t W = 0;        // windows = ceil(255 / c)
   size_t n = 0;
-  G1Affine* table[2] = {nullptr, nullptr};  // [basis] -> W x n affine points, window-major
+  // [basis] -> W x n affine points, window-major: T[w][i] = 2^(c*w) * bases[i]. Coordinates are packed
+  // canonical integers in Montgomery radix 2^261 (fp29.cuh) — the form the level-1 accumulation kernel
+  // multiplies in; (0, 0) is still the identity.
+  G1Affine* table[2] = {nullptr, nullptr};
+  // [basis] -> the n bases themselves in halo2curves' radix-2^256 form (ParamsKZG::get_g, write, downsize)
+  G1Affine* base[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -93,6 +99,16 @@ __global__ void table_next_kernel(const G1Affine* prev, G1Affine* next, size_t n
   G1X x = x_dbl_affine(p);
   for (uint32_t k = 1; k < c; k++) x = x_dbl(x);
   st_aff(next + i, x_to_affine(x));
+}
+
+// In place: radix-2^256 Montgomery coordinates -> radix-2^261 (one product per coordinate; 0 stays 0).
+__global__ void table_to_r261_kernel(G1Affine* t, size_t count) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  G1Affine p = ld_aff(t + i);
+  p.x = fq29_pack_canonical(fq29_from_r256(p.x));
+  p.y = fq29_pack_canonical(fq29_from_r256(p.y));
+  st_aff(t + i, p);
 }
 
 // ------------------------------------------------------------------ digits
@@ -285,6 +301,46 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_accum_seg_kernel(AccArgs a) {
   st_x(out + off_out[b] + (t - off_in[b] / a.T), acc);
 }
 
+// Level 1 (the hot kernel): the same task/segment structure as msm_accum_seg_kernel, but the operands are
+// window-table points (radix 2^261, packed canonical) and the accumulator lives in fp29.cuh's 9 x 29-bit
+// limbs: a mixed addition is 10 in-place-accumulating products instead of 10 CIOS products. Partial sums
+// leave in the packed radix-2^256 XYZZ form every later kernel reads (four more products per flush).
+__global__ __launch_bounds__(MSM_THREADS) void msm_accum_l1_kernel(AccArgs a) {
+  const uint32_t col = blockIdx.y;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t* off_in = a.off_in + (size_t)col * (a.nb + 1);
+  const uint32_t* off_out = a.off_out + (size_t)col * (a.nb + 1);
+  const uint32_t total = off_in[a.nb];
+  const uint32_t start = t * a.T;
+  if (start >= total) return;
+  const uint32_t end = min(start + a.T, total);
+  uint32_t lo = 0, hi = a.nb;  // largest b with off_in[b] <= start: the non-empty bucket holding `start`
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (off_in[mid] <= start) lo = mid; else hi = mid;
+  }
+  uint32_t b = lo, b_end = off_in[b + 1];
+  const uint32_t* ent = a.entries + (size_t)col * a.ecap;
+  G1X* out = a.out_list + (size_t)col * a.out_cap;
+  G1X29 acc = G1X29::inf();
+  for (uint32_t e = start; e < end; e++) {
+    if (e >= b_end) {  // crossed into the next non-empty bucket: flush
+      st_x(out + off_out[b] + (t - off_in[b] / a.T), x29_to_r256(acc));
+      acc = G1X29::inf();
+      do {
+        b++;
+        b_end = off_in[b + 1];
+      } while (e >= b_end);
+    }
+    const uint32_t id = ent[e];
+    G1Affine p = ld_aff(a.table + (id & 0x7fffffffu));
+    const bool p_inf = p.is_inf();
+    if (id >> 31) p.y = neg(p.y);  // negation of a canonical value does not depend on the Montgomery radix
+    acc = x29_add_affine(acc, fq29_unpack(p.x), fq29_unpack(p.y), p_inf);
+  }
+  st_x(out + off_out[b] + (t - off_in[b] / a.T), x29_to_r256(acc));
+}
+
 // ------------------------------------------------------------------ wavefront reductions
 __device__ __forceinline__ Fq shfl_xor_fq(const Fq& v, int m) {
   Fq r;
@@ -460,12 +516,24 @@ static int srs_build(amdzk_ctx* ctx, const void* g, const void* g_lagrange, bool
       delete s;
       ZK_FAIL(ctx, AMDZK_E_NOMEM, "srs: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     }
-    ZK_HIP(ctx, hipMemcpyAsync(s->table[b], src[b], s->n * sizeof(G1Affine), src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+    e = hipMalloc((void**)&s->base[b], s->n * sizeof(G1Affine));
+    if (e != hipSuccess) {
+      for (int j = 0; j < 2; j++) {
+        if (s->table[j]) hipFree(s->table[j]);
+        if (s->base[j]) hipFree(s->base[j]);
+      }
+      delete s;
+      ZK_FAIL(ctx, AMDZK_E_NOMEM, "srs: hipMalloc(%zu) failed: %s", s->n * sizeof(G1Affine), hipGetErrorString(e));
+    }
+    ZK_HIP(ctx, hipMemcpyAsync(s->base[b], src[b], s->n * sizeof(G1Affine), src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
                                ctx->stream));
+    ZK_HIP(ctx, hipMemcpyAsync(s->table[b], s->base[b], s->n * sizeof(G1Affine), hipMemcpyDeviceToDevice, ctx->stream));
     dim3 grid((unsigned)((s->n + 255) / 256)), block(256);
     for (uint32_t w = 1; w < s->W; w++)
       ZK_LAUNCH(ctx, "msm_table_next", table_next_kernel, grid, block, 0, s->table[b] + (size_t)(w - 1) * s->n,
                 s->table[b] + (size_t)w * s->n, s->n, s->c);
+    const size_t count = (size_t)s->W * s->n;  // all windows are built: switch the whole table to radix 2^261
+    ZK_LAUNCH(ctx, "msm_table_to_r261", table_to_r261_kernel, dim3((unsigned)((count + 255) / 256)), block, 0, s->table[b], count);
   }
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // source buffers may be released by the caller
   *out = s;
@@ -620,14 +688,14 @@ __global__ __launch_bounds__(256) void g1_decompress_kernel(const uint8_t* in, G
 size_t zk_srs_serialized_size(uint32_t k) { return 4 + 2 * ((size_t)32 << k) + 128; }
 
 int zk_srs_write(amdzk_ctx* ctx, const amdzk_srs* s, const uint8_t g2[64], const uint8_t s_g2[64], uint8_t* out, size_t cap) {
-  if (!s || !s->table[0] || !s->table[1] || !out) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_write: both bases must be resident");
+  if (!s || !s->base[0] || !s->base[1] || !out) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_write: both bases must be resident");
   const size_t need = zk_srs_serialized_size(s->k);
   if (cap < need) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_write: buffer too small (%zu < %zu)", cap, need);
   uint8_t* d = nullptr;
   ZK_TRY(zk_ws_reserve(ctx, 3, 2 * s->n * 32, (void**)&d));
   dim3 grid((unsigned)((s->n + 255) / 256)), block(256);
-  ZK_LAUNCH(ctx, "g1_compress", g1_compress_kernel, grid, block, 0, s->table[0], d, s->n);
-  ZK_LAUNCH(ctx, "g1_compress", g1_compress_kernel, grid, block, 0, s->table[1], d + s->n * 32, s->n);
+  ZK_LAUNCH(ctx, "g1_compress", g1_compress_kernel, grid, block, 0, s->base[0], d, s->n);
+  ZK_LAUNCH(ctx, "g1_compress", g1_compress_kernel, grid, block, 0, s->base[1], d + s->n * 32, s->n);
   uint32_t k = s->k;
   memcpy(out, &k, 4);
   ZK_HIP(ctx, hipMemcpyAsync(out + 4, d, 2 * s->n * 32, hipMemcpyDeviceToHost, ctx->stream));
@@ -800,7 +868,7 @@ int zk_srs_downsize(amdzk_ctx* ctx, const amdzk_srs* srs, uint32_t new_k, const 
                     amdzk_srs** out) {
   if (!srs || !out) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_downsize: null argument");
   if (new_k > srs->k) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_downsize: k %u > params k %u", new_k, srs->k);
-  if (!srs->table[0]) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_downsize: params hold no monomial basis g");
+  if (!srs->base[0]) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_downsize: params hold no monomial basis g");
   const size_t n = (size_t)1 << new_k;
   Fr wi, ni;
   memcpy(wi.l, omega_inv, 32);
@@ -810,23 +878,25 @@ int zk_srs_downsize(amdzk_ctx* ctx, const amdzk_srs* srs, uint32_t new_k, const 
   G1Affine* dl = (G1Affine*)ws;
   G1X* dx = (G1X*)(dl + n);
   Fr* tw = (Fr*)(dx + n);
-  ZK_TRY(ecfft_to_lagrange(ctx, srs->table[0], new_k, wi, ni, dx, tw, dl));  // window 0 of the table is g itself
-  return srs_build(ctx, srs->table[0], dl, true, new_k, out);
+  ZK_TRY(ecfft_to_lagrange(ctx, srs->base[0], new_k, wi, ni, dx, tw, dl));
+  return srs_build(ctx, srs->base[0], dl, true, new_k, out);
 }
 
 // ParamsKZG::get_g() / g_lagrange: the affine bases back on the host.
 int zk_srs_get(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, uint64_t* out) {
   if (!srs || !out || basis < 0 || basis > 1) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_get: bad argument");
-  if (!srs->table[basis]) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_get: basis %d was not uploaded", basis);
-  ZK_HIP(ctx, hipMemcpyAsync(out, srs->table[basis], srs->n * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream));
+  if (!srs->base[basis]) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_get: basis %d was not uploaded", basis);
+  ZK_HIP(ctx, hipMemcpyAsync(out, srs->base[basis], srs->n * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return AMDZK_OK;
 }
 
 void zk_srs_free(amdzk_ctx*, amdzk_srs* s) {
   if (!s) return;
-  for (int b = 0; b < 2; b++)
+  for (int b = 0; b < 2; b++) {
     if (s->table[b]) hipFree(s->table[b]);
+    if (s->base[b]) hipFree(s->base[b]);
+  }
   delete s;
 }
 
@@ -920,7 +990,7 @@ int zk_msm_dev_xyzz(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const Fr* d
     const size_t threads = (cap[l - 1] + T - 1) / T;
     dim3 grid((unsigned)((threads + MSM_THREADS - 1) / MSM_THREADS), (unsigned)ncols);
     if (l == 1)
-      ZK_LAUNCH(ctx, "msm_accum_l1", msm_accum_seg_kernel<true>, grid, dim3(MSM_THREADS), 0, a);
+      ZK_LAUNCH(ctx, "msm_accum_l1", msm_accum_l1_kernel, grid, dim3(MSM_THREADS), 0, a);
     else
       ZK_LAUNCH(ctx, "msm_accum_fold", msm_accum_seg_kernel<false>, grid, dim3(MSM_THREADS), 0, a);
   }

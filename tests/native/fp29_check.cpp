@@ -1,0 +1,94 @@
+// Host build of the product's 29-bit field / XYZZ code (anon-aadhaar-halo2_amd/csrc/fp29.cuh) against the
+// product's 32-bit code (bn254.cuh, itself checked against the oracle by host_field_check.cpp), with the
+// documented bounds compiled in as hard failures (FP29_CHECK_BOUNDS).
+#define FP29_CHECK_BOUNDS 1
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../anon-aadhaar-halo2_amd/csrc/fp29.cuh"
+
+using namespace bn254;
+
+static unsigned long long S = 0x9E3779B97F4A7C15ULL;
+static unsigned long long rnd() {
+  S ^= S << 13;
+  S ^= S >> 7;
+  S ^= S << 17;
+  return S;
+}
+static Fq rand_fq() {  // uniform-ish canonical value, as Montgomery form of something
+  Fq a;
+  for (int i = 0; i < 8; i++) a.l[i] = (uint32_t)rnd();
+  a.l[7] &= 0x0fffffffu;  // < 2^252 < p
+  return a;
+}
+static bool eq(const Fq& a, const Fq& b) { return memcmp(a.l, b.l, 32) == 0; }
+static bool eq_aff(const G1Affine& a, const G1Affine& b) { return eq(a.x, b.x) && eq(a.y, b.y); }
+
+int main() {
+  int fails = 0;
+  // --- field: radix changes and products
+  for (int t = 0; t < 20000; t++) {
+    Fq x = rand_fq(), y = rand_fq();
+    if (t == 0) x = Fq::zero();
+    if (t == 1) { x = Fq::one(); y = Fq::one(); }
+    if (t == 2) for (int i = 0; i < 8; i++) x.l[i] = FqP::p(i) - (i == 0);  // p - 1
+    Fq29 a = fq29_from_r256(x), b = fq29_from_r256(y);
+    if (!eq(fq29_to_r256(a), x)) { fails++; printf("radix round trip\n"); }
+    if (!eq(fq29_to_r256(fq29_mul(a, b)), mul(x, y))) { fails++; printf("mul\n"); }
+    if (!eq(fq29_to_r256(fq29_add(a, b)), add(x, y))) { fails++; printf("add\n"); }
+    if (!eq(fq29_to_r256(fq29_sub3(a, b)), sub(x, y))) { fails++; printf("sub3\n"); }
+    if (!eq(fq29_to_r256(fq29_sub10(a, fq29_add(fq29_add(b, b), b))), sub(x, add(add(y, y), y)))) { fails++; printf("sub10\n"); }
+    if (!eq(fq29_pack_canonical(fq29_unpack(x)), x)) { fails++; printf("pack\n"); }
+    if (fails > 5) return 1;
+  }
+  printf("Fq29 field ok\n");
+  // --- points: k*G for small k with the 32-bit code
+  G1Affine g;
+  g.x = Fq::one();
+  g.y = add(Fq::one(), Fq::one());
+  std::vector<G1Affine> pts;
+  {
+    G1X acc = x_from_affine(g);
+    for (int k = 1; k <= 64; k++) {
+      pts.push_back(x_to_affine(acc));
+      acc = x_add_affine(acc, g);
+    }
+  }
+  auto conv = [](const G1Affine& p, Fq29& x, Fq29& y) {  // canonical radix-2^261 table entry, as msm.hip stores it
+    x = fq29_unpack(fq29_pack_canonical(fq29_from_r256(p.x)));
+    y = fq29_unpack(fq29_pack_canonical(fq29_from_r256(p.y)));
+  };
+  for (int t = 0; t < 3000; t++) {
+    G1X a32 = G1X::inf();
+    G1X29 a29 = G1X29::inf();
+    const int len = 1 + (int)(rnd() % 40);
+    for (int i = 0; i < len; i++) {
+      G1Affine q = pts[rnd() % pts.size()];
+      const unsigned mode = (unsigned)(rnd() % 16);
+      if (mode == 0) q = G1Affine{Fq::zero(), Fq::zero()};          // identity
+      if (mode == 1 && !a32.is_inf()) q = x_to_affine(a32);         // acc + acc -> doubling
+      if (mode == 2 && !a32.is_inf()) {                              // acc + (-acc) -> identity
+        q = x_to_affine(a32);
+        q.y = neg(q.y);
+      }
+      const bool negate = (rnd() & 1) != 0 && !q.is_inf();
+      if (negate) q.y = neg(q.y);
+      Fq29 qx, qy;
+      conv(q, qx, qy);
+      a32 = x_add_affine(a32, q);
+      a29 = x29_add_affine(a29, qx, qy, q.is_inf());
+      for (int j = 0; j < 8; j++)
+        if (a29.x.l[j] >> 29 || a29.y.l[j] >> 29 || a29.zz.l[j] >> 29 || a29.zzz.l[j] >> 29) { fails++; printf("limb not normalised\n"); }
+    }
+    G1X back = x29_to_r256(a29);
+    if (a32.is_inf() != back.is_inf() || (!a32.is_inf() && !eq_aff(x_to_affine(a32), x_to_affine(back)))) {
+      fails++;
+      printf("point chain mismatch at test %d\n", t);
+      if (fails > 5) return 1;
+    }
+  }
+  printf(fails ? "FAILED\n" : "G1X29 ok\n");
+  return fails != 0;
+}
