@@ -240,6 +240,42 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* src, uin
 }
 
 // ------------------------------------------------------------------ accumulation levels
+// From the table gather to the last fold everything runs on fp29.cuh's 9 x 29-bit limbs in Montgomery radix
+// 2^261. Partial sums cross HBM as raw G1X29 (36 words, 144 B): limbs normalised, values only lazily
+// reduced (x < 9p, y < 5p, zz, zzz < 2p) — no conversion or reduction on the way out or in. Only the one
+// result per column is converted to the packed radix-2^256 XYZZ that zk_msm_finish and the callers read.
+__device__ __forceinline__ G1X29 ld_x29(const G1X29* p) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint32_t w[36];
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    uint4 v = q[i];
+    w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+  }
+  G1X29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    r.x.l[i] = w[i];
+    r.y.l[i] = w[9 + i];
+    r.zz.l[i] = w[18 + i];
+    r.zzz.l[i] = w[27 + i];
+  }
+  return r;
+}
+__device__ __forceinline__ void st_x29(G1X29* p, const G1X29& v) {
+  uint32_t w[36];
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    w[i] = v.x.l[i];
+    w[9 + i] = v.y.l[i];
+    w[18 + i] = v.zz.l[i];
+    w[27 + i] = v.zzz.l[i];
+  }
+  uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+  for (int i = 0; i < 9; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
 struct AccArgs {
   const uint32_t* off_in;   // [ncols][nb+1] offsets of the input list per bucket
   const uint32_t* off_out;  // [ncols][nb+1] task offsets per bucket (ceil(cnt/T))
@@ -248,9 +284,9 @@ struct AccArgs {
   const uint32_t* entries;  // level 1 input
   size_t ecap;
   const G1Affine* table;
-  const G1X* in_list;       // level >= 2 input
+  const G1X29* in_list;     // level >= 2 input
   size_t in_cap;
-  G1X* out_list;
+  G1X29* out_list;
   size_t out_cap;
 };
 
@@ -259,7 +295,8 @@ struct AccArgs {
 // buckets they belong to, and emits one partial sum per bucket segment it crosses (slot
 // off_out[b] + (t - off_in[b]/T)). Every lane of a wavefront performs the same number of additions,
 // so skewed witness columns (thousands of tiny buckets next to a few huge ones) no longer leave most
-// lanes idle behind the longest task.
+// lanes idle behind the longest task. FIRST is the hot kernel of the whole prover: a mixed addition is
+// 10 in-place-accumulating products (fq29_mul) on a window-table point (packed canonical, radix 2^261).
 template <bool FIRST>
 __global__ __launch_bounds__(MSM_THREADS) void msm_accum_seg_kernel(AccArgs a) {
   const uint32_t col = blockIdx.y;
@@ -277,139 +314,113 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_accum_seg_kernel(AccArgs a) {
   }
   uint32_t b = lo, b_end = off_in[b + 1];
   const uint32_t* ent = FIRST ? a.entries + (size_t)col * a.ecap : nullptr;
-  const G1X* in = FIRST ? nullptr : a.in_list + (size_t)col * a.in_cap;
-  G1X* out = a.out_list + (size_t)col * a.out_cap;
-  G1X acc = G1X::inf();
-  for (uint32_t e = start; e < end; e++) {
-    if (e >= b_end) {  // crossed into the next non-empty bucket: flush
-      st_x(out + off_out[b] + (t - off_in[b] / a.T), acc);
-      acc = G1X::inf();
-      do {
-        b++;
-        b_end = off_in[b + 1];
-      } while (e >= b_end);
-    }
-    if (FIRST) {
-      uint32_t id = ent[e];
-      G1Affine p = ld_aff(a.table + (id & 0x7fffffffu));
-      if (id >> 31) p.y = neg(p.y);
-      acc = x_add_affine(acc, p);
-    } else {
-      acc = x_add(acc, ld_x(in + e));
-    }
-  }
-  st_x(out + off_out[b] + (t - off_in[b] / a.T), acc);
-}
-
-// Level 1 (the hot kernel): the same task/segment structure as msm_accum_seg_kernel, but the operands are
-// window-table points (radix 2^261, packed canonical) and the accumulator lives in fp29.cuh's 9 x 29-bit
-// limbs: a mixed addition is 10 in-place-accumulating products instead of 10 CIOS products. Partial sums
-// leave in the packed radix-2^256 XYZZ form every later kernel reads (four more products per flush).
-__global__ __launch_bounds__(MSM_THREADS) void msm_accum_l1_kernel(AccArgs a) {
-  const uint32_t col = blockIdx.y;
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t* off_in = a.off_in + (size_t)col * (a.nb + 1);
-  const uint32_t* off_out = a.off_out + (size_t)col * (a.nb + 1);
-  const uint32_t total = off_in[a.nb];
-  const uint32_t start = t * a.T;
-  if (start >= total) return;
-  const uint32_t end = min(start + a.T, total);
-  uint32_t lo = 0, hi = a.nb;  // largest b with off_in[b] <= start: the non-empty bucket holding `start`
-  while (hi - lo > 1) {
-    uint32_t mid = (lo + hi) >> 1;
-    if (off_in[mid] <= start) lo = mid; else hi = mid;
-  }
-  uint32_t b = lo, b_end = off_in[b + 1];
-  const uint32_t* ent = a.entries + (size_t)col * a.ecap;
-  G1X* out = a.out_list + (size_t)col * a.out_cap;
+  const G1X29* in = FIRST ? nullptr : a.in_list + (size_t)col * a.in_cap;
+  G1X29* out = a.out_list + (size_t)col * a.out_cap;
   G1X29 acc = G1X29::inf();
   for (uint32_t e = start; e < end; e++) {
     if (e >= b_end) {  // crossed into the next non-empty bucket: flush
-      st_x(out + off_out[b] + (t - off_in[b] / a.T), x29_to_r256(acc));
+      st_x29(out + off_out[b] + (t - off_in[b] / a.T), acc);
       acc = G1X29::inf();
       do {
         b++;
         b_end = off_in[b + 1];
       } while (e >= b_end);
     }
-    const uint32_t id = ent[e];
-    G1Affine p = ld_aff(a.table + (id & 0x7fffffffu));
-    const bool p_inf = p.is_inf();
-    if (id >> 31) p.y = neg(p.y);  // negation of a canonical value does not depend on the Montgomery radix
-    acc = x29_add_affine(acc, fq29_unpack(p.x), fq29_unpack(p.y), p_inf);
+    if (FIRST) {
+      const uint32_t id = ent[e];
+      G1Affine p = ld_aff(a.table + (id & 0x7fffffffu));
+      const bool p_inf = p.is_inf();
+      if (id >> 31) p.y = neg(p.y);  // negating a canonical value does not depend on the Montgomery radix
+      acc = x29_add_affine(acc, fq29_unpack(p.x), fq29_unpack(p.y), p_inf);
+    } else {
+      acc = x29_add(acc, ld_x29(in + e));
+    }
   }
-  st_x(out + off_out[b] + (t - off_in[b] / a.T), x29_to_r256(acc));
+  st_x29(out + off_out[b] + (t - off_in[b] / a.T), acc);
 }
 
 // ------------------------------------------------------------------ wavefront reductions
+__device__ __forceinline__ G1X29 shfl_xor_x29(const G1X29& v, int m) {
+  G1X29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    r.x.l[i] = __shfl_xor(v.x.l[i], m, 64);
+    r.y.l[i] = __shfl_xor(v.y.l[i], m, 64);
+    r.zz.l[i] = __shfl_xor(v.zz.l[i], m, 64);
+    r.zzz.l[i] = __shfl_xor(v.zzz.l[i], m, 64);
+  }
+  return r;
+}
+// All 64 lanes end with the sum of the 64 inputs.
+__device__ __forceinline__ G1X29 wave_sum29(G1X29 v) {
+#pragma unroll 1
+  for (int m = 32; m >= 1; m >>= 1) v = x29_add(v, shfl_xor_x29(v, m));
+  return v;
+}
+// The 32-bit flavour, for the start-up-only group FFT below.
 __device__ __forceinline__ Fq shfl_xor_fq(const Fq& v, int m) {
   Fq r;
 #pragma unroll
   for (int i = 0; i < 8; i++) r.l[i] = __shfl_xor(v.l[i], m, 64);
   return r;
 }
-__device__ __forceinline__ G1X shfl_xor_x(const G1X& v, int m) {
-  G1X r;
-  r.x = shfl_xor_fq(v.x, m);
-  r.y = shfl_xor_fq(v.y, m);
-  r.zz = shfl_xor_fq(v.zz, m);
-  r.zzz = shfl_xor_fq(v.zzz, m);
-  return r;
-}
-// All 64 lanes end with the sum of the 64 inputs.
-__device__ __forceinline__ G1X wave_sum(G1X v) {
-#pragma unroll 1
-  for (int m = 32; m >= 1; m >>= 1) v = x_add(v, shfl_xor_x(v, m));
-  return v;
-}
 
 // Final level: one lane per bucket folds whatever is left and writes the dense bucket array. A bucket
 // that still holds more than FINAL_SERIAL partial sums (a witness column where one value dominates)
 // is finished by the whole wavefront: lanes take strided shares, then a shuffle-tree sum.
 constexpr uint32_t FINAL_SERIAL = 6;
-__global__ __launch_bounds__(64) void msm_accum_final_kernel(const uint32_t* off_in_all, uint32_t nb, const G1X* in_list, size_t in_cap,
-                                                             G1X* dense) {
+__global__ __launch_bounds__(64) void msm_accum_final_kernel(const uint32_t* off_in_all, uint32_t nb, const G1X29* in_list, size_t in_cap,
+                                                             G1X29* dense) {
   const uint32_t col = blockIdx.y, lane = threadIdx.x;
   const uint32_t b = blockIdx.x * 64 + lane;  // nb is a multiple of 64
   const uint32_t* off_in = off_in_all + (size_t)col * (nb + 1);
-  const G1X* in = in_list + (size_t)col * in_cap;
+  const G1X29* in = in_list + (size_t)col * in_cap;
   const uint32_t lo = off_in[b], hi = off_in[b + 1];
   const uint32_t serial_end = min(hi, lo + FINAL_SERIAL);
-  G1X acc = G1X::inf();
-  for (uint32_t e = lo; e < serial_end; e++) acc = x_add(acc, ld_x(in + e));
+  G1X29 acc = G1X29::inf();
+  for (uint32_t e = lo; e < serial_end; e++) acc = x29_add(acc, ld_x29(in + e));
   unsigned long long heavy = __ballot(hi > serial_end);
   while (heavy) {
     const int src = __ffsll((long long)heavy) - 1;
     heavy &= heavy - 1;
     const uint32_t h_lo = __shfl(serial_end, src, 64), h_hi = __shfl(hi, src, 64);
-    G1X part = G1X::inf();
-    for (uint32_t e = h_lo + lane; e < h_hi; e += 64) part = x_add(part, ld_x(in + e));
-    part = wave_sum(part);
-    if ((int)lane == src) acc = x_add(acc, part);
+    G1X29 part = G1X29::inf();
+    for (uint32_t e = h_lo + lane; e < h_hi; e += 64) part = x29_add(part, ld_x29(in + e));
+    part = wave_sum29(part);
+    if ((int)lane == src) acc = x29_add(acc, part);
   }
-  st_x(dense + (size_t)col * nb + b, acc);
+  st_x29(dense + (size_t)col * nb + b, acc);
 }
 
 // rows[col][g] = sum_r dense[col][64g + r]   (one wave per g)
 // cols[col][r] = sum_g dense[col][64g + r]   (one wave per r)
-__global__ __launch_bounds__(64) void msm_rowcol_kernel(const G1X* dense, uint32_t nb, G1X* rows,
-                                                         G1X* cols) {
+__global__ __launch_bounds__(64) void msm_rowcol_kernel(const G1X29* dense, uint32_t nb, G1X29* rows, G1X29* cols) {
   const uint32_t col = blockIdx.y, lane = threadIdx.x;
   const uint32_t G = nb >> 6;
-  const G1X* d = dense + (size_t)col * nb;
+  const G1X29* d = dense + (size_t)col * nb;
   if (blockIdx.x < G) {
     const uint32_t g = blockIdx.x;
-    G1X s = wave_sum(ld_x(d + 64 * g + lane));
-    if (lane == 0) st_x(rows + (size_t)col * G + g, s);
+    G1X29 s = wave_sum29(ld_x29(d + 64 * g + lane));
+    if (lane == 0) st_x29(rows + (size_t)col * G + g, s);
   } else {
     const uint32_t r = blockIdx.x - G;
-    G1X acc = G1X::inf();
-    for (uint32_t g = lane; g < G; g += 64) acc = x_add(acc, ld_x(d + 64 * g + r));
-    G1X s = wave_sum(acc);
-    if (lane == 0) st_x(cols + (size_t)col * 64 + r, s);
+    G1X29 acc = G1X29::inf();
+    for (uint32_t g = lane; g < G; g += 64) acc = x29_add(acc, ld_x29(d + 64 * g + r));
+    G1X29 s = wave_sum29(acc);
+    if (lane == 0) st_x29(cols + (size_t)col * 64 + r, s);
   }
 }
 
+__device__ __forceinline__ G1X29 x29_mul_small(const G1X29& p, uint32_t k, int nbits) {
+  G1X29 acc = G1X29::inf();
+#pragma unroll 1
+  for (int b = nbits - 1; b >= 0; b--) {
+    acc = x29_dbl(acc);
+    if ((k >> b) & 1) acc = x29_add(acc, p);
+  }
+  return acc;
+}
+// 32-bit flavour (group FFT, start-up only)
 __device__ __forceinline__ G1X x_mul_small(const G1X& p, uint32_t k, int nbits) {
   G1X acc = G1X::inf();
 #pragma unroll 1
@@ -424,37 +435,38 @@ __device__ __forceinline__ G1X x_mul_small(const G1X& p, uint32_t k, int nbits) 
 //          = sum_r r*cols[r] + 64 * (sum_g g*rows[g]) + sum_g rows[g].
 // Three independent reductions on separate wavefronts (W = ceil(G/64) waves for each row sum, one for
 // the columns), so the dependent chain is a 6..9-bit double-and-add, one shuffle tree, six doublings
-// and a handful of additions — the kernel is pure latency (one workgroup per column).
-__global__ __launch_bounds__(1024) void msm_fold_kernel(const G1X* rows, const G1X* cols, uint32_t nb, G1X* out, int split) {
-  __shared__ G1X part[17];
+// and a handful of additions — the kernel is pure latency (one workgroup per column). The result leaves
+// in the packed radix-2^256 XYZZ form (x29_to_r256): the only radix conversion of the whole MSM.
+__global__ __launch_bounds__(576) void msm_fold_kernel(const G1X29* rows, const G1X29* cols, uint32_t nb, G1X* out, int split) {
+  __shared__ G1X29 part[17];
   const uint32_t col = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const uint32_t G = nb >> 6, W = (G + 63) >> 6;
   const int gbits = 32 - __clz(G > 1 ? G - 1 : 1);
   if (wv < W) {  // sum_g g*rows[g]  (and, when not split, sum_g rows[g] as well)
     const uint32_t g = wv * 64 + lane;
-    G1X v = g < G ? ld_x(rows + (size_t)col * G + g) : G1X::inf();
-    G1X s = wave_sum(x_mul_small(v, g, gbits));
+    G1X29 v = g < G ? ld_x29(rows + (size_t)col * G + g) : G1X29::inf();
+    G1X29 s = wave_sum29(x29_mul_small(v, g, gbits));
     if (lane == 0) part[wv] = s;
     if (!split) {
-      G1X u = wave_sum(v);
+      G1X29 u = wave_sum29(v);
       if (lane == 0) part[8 + wv] = u;
     }
   } else if (split && wv < 2 * W) {  // sum_g rows[g]
     const uint32_t g = (wv - W) * 64 + lane;
-    G1X u = wave_sum(g < G ? ld_x(rows + (size_t)col * G + g) : G1X::inf());
+    G1X29 u = wave_sum29(g < G ? ld_x29(rows + (size_t)col * G + g) : G1X29::inf());
     if (lane == 0) part[8 + wv - W] = u;
   } else {  // sum_r r*cols[r]
-    G1X c = wave_sum(x_mul_small(ld_x(cols + (size_t)col * 64 + lane), lane, 6));
+    G1X29 c = wave_sum29(x29_mul_small(ld_x29(cols + (size_t)col * 64 + lane), lane, 6));
     if (lane == 0) part[16] = c;
   }
   __syncthreads();
   if (t == 0) {
-    G1X acc = part[0];
-    for (uint32_t i = 1; i < W; i++) acc = x_add(acc, part[i]);
+    G1X29 acc = part[0];
+    for (uint32_t i = 1; i < W; i++) acc = x29_add(acc, part[i]);
 #pragma unroll 1
-    for (int i = 0; i < 6; i++) acc = x_dbl(acc);
-    for (uint32_t i = 0; i < W; i++) acc = x_add(acc, part[8 + i]);
-    st_x(out + col, x_add(acc, part[16]));
+    for (int i = 0; i < 6; i++) acc = x29_dbl(acc);
+    for (uint32_t i = 0; i < W; i++) acc = x29_add(acc, part[8 + i]);
+    st_x(out + col, x29_to_r256(x29_add(acc, part[16])));
   }
 }
 
@@ -939,21 +951,22 @@ int zk_msm_dev_xyzz(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const Fr* d
   for (int l = 0; l <= NLEV; l++) o_off[l] = take(ncols * (nb + 1) * 4);
   const size_t o_ent = take(ncols * ecap * 4);
   o_list[0] = 0;
-  for (int l = 1; l <= NLEV; l++) o_list[l] = take(ncols * cap[l] * sizeof(G1X));
-  const size_t o_dense = take(ncols * nb * sizeof(G1X));
+  for (int l = 1; l <= NLEV; l++) o_list[l] = take(ncols * cap[l] * sizeof(G1X29));
+  const size_t o_dense = take(ncols * nb * sizeof(G1X29));
   const size_t G = nb >> 6;
-  const size_t o_rows = take(ncols * G * sizeof(G1X)), o_cols = take(ncols * 64 * sizeof(G1X));
+  const size_t o_rows = take(ncols * G * sizeof(G1X29)), o_cols = take(ncols * 64 * sizeof(G1X29));
   const size_t o_out = take(ncols * sizeof(G1X));
   char* ws = nullptr;
   ZK_TRY(zk_ws_reserve(ctx, 1, o, (void**)&ws));
   uint32_t* blk_hist = (uint32_t*)(ws + o_bh);
   uint32_t* cnt = (uint32_t*)(ws + o_cnt);
   uint32_t* off[NLEV + 1];
-  G1X* list[NLEV + 1];
-  for (int l = 0; l <= NLEV; l++) off[l] = (uint32_t*)(ws + o_off[l]), list[l] = (G1X*)(ws + o_list[l]);
+  G1X29* list[NLEV + 1];
+  for (int l = 0; l <= NLEV; l++) off[l] = (uint32_t*)(ws + o_off[l]), list[l] = (G1X29*)(ws + o_list[l]);
   uint32_t* entries = (uint32_t*)(ws + o_ent);
-  G1X* dense = (G1X*)(ws + o_dense);
-  G1X *rows = (G1X*)(ws + o_rows), *cols = (G1X*)(ws + o_cols), *outp = (G1X*)(ws + o_out);
+  G1X29* dense = (G1X29*)(ws + o_dense);
+  G1X29 *rows = (G1X29*)(ws + o_rows), *cols = (G1X29*)(ws + o_cols);
+  G1X* outp = (G1X*)(ws + o_out);
 
   DigitArgs da;
   da.scalars = d_scalars;
@@ -990,15 +1003,15 @@ int zk_msm_dev_xyzz(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const Fr* d
     const size_t threads = (cap[l - 1] + T - 1) / T;
     dim3 grid((unsigned)((threads + MSM_THREADS - 1) / MSM_THREADS), (unsigned)ncols);
     if (l == 1)
-      ZK_LAUNCH(ctx, "msm_accum_l1", msm_accum_l1_kernel, grid, dim3(MSM_THREADS), 0, a);
+      ZK_LAUNCH(ctx, "msm_accum_l1", msm_accum_seg_kernel<true>, grid, dim3(MSM_THREADS), 0, a);
     else
       ZK_LAUNCH(ctx, "msm_accum_fold", msm_accum_seg_kernel<false>, grid, dim3(MSM_THREADS), 0, a);
   }
   ZK_LAUNCH(ctx, "msm_accum_final", msm_accum_final_kernel, dim3(nb / 64, (unsigned)ncols), dim3(64), 0, off[NLEV], nb, list[NLEV], cap[NLEV],
             dense);
   ZK_LAUNCH(ctx, "msm_rowcol", msm_rowcol_kernel, dim3((unsigned)(G + 64), (unsigned)ncols), dim3(64), 0, dense, nb, rows, cols);
-  const unsigned fold_w = (unsigned)((G + 63) / 64);  // <= 8
-  const int fold_split = 2 * fold_w + 1 <= 16;
+  const unsigned fold_w = (unsigned)((G + 63) / 64);  // 1, 2, 4 or 8 (c <= 16)
+  const int fold_split = fold_w <= 4;                  // at most 9 wavefronts per workgroup either way (launch bound 576)
   ZK_LAUNCH(ctx, "msm_fold", msm_fold_kernel, dim3((unsigned)ncols), dim3(64 * ((fold_split ? 2 : 1) * fold_w + 1)), 0, rows, cols, nb, outp,
             fold_split);
   *d_out = outp;

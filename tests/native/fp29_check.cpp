@@ -89,6 +89,73 @@ int main() {
       if (fails > 5) return 1;
     }
   }
+  // --- XYZZ + XYZZ and doubling: random trees of partial sums, as the fold levels build them
+  auto lift = [&](const G1Affine& q) {
+    Fq29 qx, qy;
+    conv(q, qx, qy);
+    return x29_add_affine(G1X29::inf(), qx, qy, q.is_inf());
+  };
+  for (int t = 0; t < 3000; t++) {
+    std::vector<G1X> v32;
+    std::vector<G1X29> v29;
+    const int m = 2 + (int)(rnd() % 12);
+    for (int i = 0; i < m; i++) {  // leaves: short chains, so ZZ != 1 and the lazy bounds are exercised
+      G1X a = G1X::inf();
+      G1X29 b = G1X29::inf();
+      const int len = (int)(rnd() % 4);
+      for (int j = 0; j < len; j++) {
+        G1Affine q = pts[rnd() % pts.size()];
+        if (rnd() & 1) q.y = neg(q.y);
+        Fq29 qx, qy;
+        conv(q, qx, qy);
+        a = x_add_affine(a, q);
+        b = x29_add_affine(b, qx, qy, false);
+      }
+      v32.push_back(a);
+      v29.push_back(b);
+    }
+    while (v32.size() > 1) {
+      size_t i = rnd() % v32.size(), j = rnd() % v32.size();
+      const unsigned mode = (unsigned)(rnd() % 8);
+      G1X r32;
+      G1X29 r29;
+      if (mode == 0) {  // doubling
+        r32 = x_dbl(v32[i]);
+        r29 = x29_dbl(v29[i]);
+        j = i;
+      } else if (mode == 1) {  // a + a through the addition formula
+        r32 = x_add(v32[i], v32[i]);
+        r29 = x29_add(v29[i], v29[i]);
+        j = i;
+      } else if (mode == 2 && !v32[i].is_inf()) {  // a + (-a) with a different representative of -a
+        G1Affine q = x_to_affine(v32[i]);
+        q.y = neg(q.y);
+        r32 = x_add(v32[i], x_from_affine(q));
+        r29 = x29_add(v29[i], lift(q));
+        j = i;
+      } else {
+        if (i == j) continue;
+        r32 = x_add(v32[i], v32[j]);
+        r29 = x29_add(v29[i], v29[j]);
+      }
+      G1X back = x29_to_r256(r29);
+      if (r32.is_inf() != back.is_inf() || (!r32.is_inf() && !eq_aff(x_to_affine(r32), x_to_affine(back)))) {
+        fails++;
+        printf("x29_add/x29_dbl mismatch at test %d mode %u\n", t, mode);
+        if (fails > 5) return 1;
+      }
+      v32[i] = r32;
+      v29[i] = r29;
+      if (j != i) {
+        v32.erase(v32.begin() + j);
+        v29.erase(v29.begin() + j);
+      }
+      if (mode <= 2 && v32.size() > 1 && (rnd() & 3) == 0) {
+        v32.pop_back();
+        v29.pop_back();
+      }
+    }
+  }
   printf(fails ? "FAILED\n" : "G1X29 ok\n");
   return fails != 0;
 }
