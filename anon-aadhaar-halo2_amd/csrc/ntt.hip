@@ -21,6 +21,7 @@
 #include <string.h>
 
 #include "common.hpp"
+#include "fp29.cuh"
 
 using namespace bn254;
 
@@ -33,7 +34,7 @@ struct NttPassArgs {
   Fr* out;
   size_t in_col_stride;   // elements between consecutive columns (batch)
   size_t out_col_stride;
-  const Fr* tw;           // omega^i, i < n/2
+  const Fr* tw;           // omega^i, i < n/2, each stored as omega^i * 2^261 (packed canonical): see fp29.cuh "mixed radix"
   uint32_t log_n;
   uint32_t s;             // log2 of this step's sub-transform length n_p
   uint32_t log_c;         // log2 of C (tile = 2^s x C elements)
@@ -46,8 +47,8 @@ struct NttPassArgs {
   uint32_t npass;
   uint32_t in_len;        // first step: elements at index >= in_len read as zero (zero padding)
   uint32_t flags;
-  Fr in_c[2];             // first step, IN_COSET: element i is multiplied by in_c[i%3 - 1] when i%3 != 0
-  Fr out_c[3];            // last step, OUT_MUL: element j is multiplied by out_c[j%3]
+  Fr in_c[2];             // first step, IN_COSET: element i is multiplied by in_c[i%3 - 1] when i%3 != 0   (radix 2^261)
+  Fr out_c[3];            // last step, OUT_MUL: element j is multiplied by out_c[j%3]                       (radix 2^261)
 };
 
 constexpr uint32_t F_IN_COSET = 1u;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
       uint32_t x = e >> a.log_c, c = e & (C - 1);
       size_t gi = LAST ? (in_base + (size_t)c * row_stride + x) : (in_base + (size_t)x * row_stride + c);
       uint32_t m = (uint32_t)(gi % 3);
-      if (m != 0 && gi < a.in_len) L[e] = mul(L[e], a.in_c[m - 1]);
+      if (m != 0 && gi < a.in_len) L[e] = fr29_mul_const(L[e], a.in_c[m - 1]);
     }
     __syncthreads();
   }
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
       Fr u = L[e0], v = L[e1];
       L[e0] = add(u, v);
       Fr d = sub(u, v);
-      if (st > 0) d = mul(d, TW[i << (a.s - 1 - st)]);
+      if (st > 0) d = fr29_mul_const(d, TW[i << (a.s - 1 - st)]);
       L[e1] = d;
     }
     __syncthreads();
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
       uint32_t i_next = (lo_base + c) >> sh_next;
       uint32_t Jp = J_prev + (j << a.log_prev);
       uint32_t ex = (i_next * Jp) << log_g;
-      if (ex != 0) x = mul(x, tw_lookup(a.tw, ex, log_n));
+      if (ex != 0) x = fr29_mul_const(x, tw_lookup(a.tw, ex, log_n));
       st_fr(out + in_base + (size_t)j * row_stride + c, x);
     }
   } else {
@@ -184,13 +185,15 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
       uint32_t j = e >> a.log_c, rr = e & (C - 1);
       Fr x = L[(brev(j, a.s) << a.log_c) + rr];
       size_t oi = out_base + rr + ((size_t)j << log_ostride);
-      if (a.flags & F_OUT_MUL) x = mul(x, a.out_c[oi % 3]);
+      if (a.flags & F_OUT_MUL) x = fr29_mul_const(x, a.out_c[oi % 3]);
       st_fr(out + oi, x);
     }
   }
 }
 
-// tw[i] = omega^i for i < count. Each thread raises omega to its chunk start, then walks.
+// tw[i] = omega^i for i < count, stored as the packed canonical integer omega^i * 2^261 (the radix the
+// butterflies' constant operand is kept in; negation in tw_lookup is radix-independent). Each thread raises
+// omega to its chunk start, then walks.
 __global__ void twiddle_gen_kernel(Fr* tw, Fr omega, uint32_t count, uint32_t chunk) {
   uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t start = (uint64_t)t * chunk;
@@ -198,7 +201,7 @@ __global__ void twiddle_gen_kernel(Fr* tw, Fr omega, uint32_t count, uint32_t ch
   Fr cur = pow_u64(omega, start);
   uint32_t end = (uint32_t)((start + chunk < count) ? start + chunk : count);
   for (uint32_t i = (uint32_t)start; i < end; i++) {
-    st_fr(tw + i, cur);
+    st_fr(tw + i, fr29_const_to_r261(cur));
     cur = mul(cur, omega);
   }
 }
@@ -289,14 +292,17 @@ int zk_ntt_ex(amdzk_ctx* ctx, const Fr* d_in, size_t in_stride, Fr* d_out, size_
   a.log_n1 = plan.s[0];
   a.log_n2 = plan.s[1];
   a.in_len = in_len;
+  // callers pass constants in halo2curves' radix-2^256 form; the kernels want c * 2^261 = (32 c) * 2^256
+  Fr k32 = Fr::one();
+  for (int i = 0; i < 5; i++) k32 = add(k32, k32);
   if (in_coset) {
-    a.in_c[0] = in_coset[0];
-    a.in_c[1] = in_coset[1];
+    a.in_c[0] = mul(in_coset[0], k32);
+    a.in_c[1] = mul(in_coset[1], k32);
   }
   if (out_mul) {
-    a.out_c[0] = out_mul[0];
-    a.out_c[1] = out_mul[1];
-    a.out_c[2] = out_mul[2];
+    a.out_c[0] = mul(out_mul[0], k32);
+    a.out_c[1] = mul(out_mul[1], k32);
+    a.out_c[2] = mul(out_mul[2], k32);
   }
   uint32_t log_prev = 0;
   for (uint32_t p = 0; p < plan.npass; p++) {

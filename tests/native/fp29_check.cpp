@@ -36,14 +36,37 @@ int main() {
     if (t == 2) for (int i = 0; i < 8; i++) x.l[i] = FqP::p(i) - (i == 0);  // p - 1
     Fq29 a = fq29_from_r256(x), b = fq29_from_r256(y);
     if (!eq(fq29_to_r256(a), x)) { fails++; printf("radix round trip\n"); }
-    if (!eq(fq29_to_r256(fq29_mul(a, b)), mul(x, y))) { fails++; printf("mul\n"); }
-    if (!eq(fq29_to_r256(fq29_add(a, b)), add(x, y))) { fails++; printf("add\n"); }
-    if (!eq(fq29_to_r256(fq29_sub3(a, b)), sub(x, y))) { fails++; printf("sub3\n"); }
-    if (!eq(fq29_to_r256(fq29_sub10(a, fq29_add(fq29_add(b, b), b))), sub(x, add(add(y, y), y)))) { fails++; printf("sub10\n"); }
+    if (!eq(fq29_to_r256(f29_mul(a, b)), mul(x, y))) { fails++; printf("mul\n"); }
+    if (!eq(fq29_to_r256(f29_add(a, b)), add(x, y))) { fails++; printf("add\n"); }
+    if (!eq(fq29_to_r256(f29_sub3(a, b)), sub(x, y))) { fails++; printf("sub3\n"); }
+    if (!eq(fq29_to_r256(f29_sub10(a, f29_add(f29_add(b, b), b))), sub(x, add(add(y, y), y)))) { fails++; printf("sub10\n"); }
     if (!eq(fq29_pack_canonical(fq29_unpack(x)), x)) { fails++; printf("pack\n"); }
     if (fails > 5) return 1;
   }
   printf("Fq29 field ok\n");
+  // --- scalar field, mixed radix as ntt.hip uses it: data in radix 2^256 times a constant kept in radix 2^261
+  for (int t = 0; t < 20000; t++) {
+    Fr x, c;
+    for (int i = 0; i < 8; i++) {
+      x.l[i] = (uint32_t)rnd();
+      c.l[i] = (uint32_t)rnd();
+    }
+    x.l[7] &= 0x0fffffffu;
+    c.l[7] &= 0x0fffffffu;
+    if (t == 0) x = Fr::zero();
+    if (t == 1) c = Fr::one();
+    if (t == 2) for (int i = 0; i < 8; i++) x.l[i] = FrP::p(i) - (i == 0);  // r - 1
+    Fr c261 = fr29_const_to_r261(c);
+    Fr want = mul(x, c);
+    Fr got = fr29_mul_const(x, c261);
+    if (memcmp(got.l, want.l, 32) != 0) { fails++; printf("Fr mixed-radix product\n"); if (fails > 5) return 1; }
+    // negating the packed constant commutes with the radix change (tw_lookup negates table entries)
+    if (!c.is_zero()) {
+      Fr got_n = fr29_mul_const(x, neg(c261)), want_n = mul(x, neg(c));
+      if (memcmp(got_n.l, want_n.l, 32) != 0) { fails++; printf("Fr negated constant\n"); if (fails > 5) return 1; }
+    }
+  }
+  printf("Fr29 mixed radix ok\n");
   // --- points: k*G for small k with the 32-bit code
   G1Affine g;
   g.x = Fq::one();
