@@ -49,10 +49,12 @@ struct NttPassArgs {
   uint32_t flags;
   Fr in_c[2];             // first step, IN_COSET: element i is multiplied by in_c[i%3 - 1] when i%3 != 0   (radix 2^261)
   Fr out_c[3];            // last step, OUT_MUL: element j is multiplied by out_c[j%3]                       (radix 2^261)
+  Fr in_c0;               // first step, IN_ALL: elements with i%3 == 0 are multiplied too (a global input factor)
 };
 
 constexpr uint32_t F_IN_COSET = 1u;
 constexpr uint32_t F_OUT_MUL = 2u;
+constexpr uint32_t F_IN_ALL = 4u;
 
 __device__ __forceinline__ uint32_t brev(uint32_t x, uint32_t bits) {
   return bits == 0 ? 0u : (__brev(x) >> (32 - bits));
@@ -141,7 +143,10 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
       uint32_t x = e >> a.log_c, c = e & (C - 1);
       size_t gi = LAST ? (in_base + (size_t)c * row_stride + x) : (in_base + (size_t)x * row_stride + c);
       uint32_t m = (uint32_t)(gi % 3);
-      if (m != 0 && gi < a.in_len) L[e] = fr29_mul_const(L[e], a.in_c[m - 1]);
+      if (gi < a.in_len) {
+        if (m != 0) L[e] = fr29_mul_const(L[e], a.in_c[m - 1]);
+        else if (a.flags & F_IN_ALL) L[e] = fr29_mul_const(L[e], a.in_c0);
+      }
     }
     __syncthreads();
   }
@@ -269,7 +274,7 @@ Plan make_plan(uint32_t log_n, uint32_t tile_log) {
 //   in_coset : if non-null, 2 constants applied to input element i with i%3 = 1, 2
 //   out_mul  : if non-null, 3 constants applied to output element j by j%3
 int zk_ntt_ex(amdzk_ctx* ctx, const Fr* d_in, size_t in_stride, Fr* d_out, size_t out_stride, uint32_t log_n,
-              const uint64_t omega[4], size_t ncols, uint32_t in_len, const Fr* in_coset, const Fr* out_mul) {
+              const uint64_t omega[4], size_t ncols, uint32_t in_len, const Fr* in_coset, const Fr* out_mul, const Fr* in_first) {
   if (log_n > 27) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "ntt: log_n %u > 27", log_n);
   if (ncols == 0) return AMDZK_OK;
   const size_t n = (size_t)1 << log_n;
@@ -298,6 +303,7 @@ int zk_ntt_ex(amdzk_ctx* ctx, const Fr* d_in, size_t in_stride, Fr* d_out, size_
   if (in_coset) {
     a.in_c[0] = mul(in_coset[0], k32);
     a.in_c[1] = mul(in_coset[1], k32);
+    if (in_first) a.in_c0 = mul(*in_first, k32);
   }
   if (out_mul) {
     a.out_c[0] = mul(out_mul[0], k32);
@@ -320,7 +326,7 @@ int zk_ntt_ex(amdzk_ctx* ctx, const Fr* d_in, size_t in_stride, Fr* d_out, size_
     }
     a.log_c = lc;
     a.flags = 0;
-    if (p == 0 && in_coset) a.flags |= F_IN_COSET;
+    if (p == 0 && in_coset) a.flags |= F_IN_COSET | (in_first ? F_IN_ALL : 0u);
     if (last && out_mul) a.flags |= F_OUT_MUL;
     // first step reads the caller's input, last step writes the caller's output, the workspace
     // carries the intermediate layout. A single-step transform covers a column with one tile (all
@@ -354,7 +360,7 @@ int zk_ntt_dev(amdzk_ctx* ctx, Fr* d_a, uint32_t log_n, const uint64_t omega[4],
   if (flags & AMDZK_NTT_SCALE_NINV) {
     Fr ninv = zk_fr_inv_pow2(log_n);
     Fr oc[3] = {ninv, ninv, ninv};
-    return zk_ntt_ex(ctx, d_a, col_stride, d_a, col_stride, log_n, omega, ncols, 0, nullptr, oc);
+    return zk_ntt_ex(ctx, d_a, col_stride, d_a, col_stride, log_n, omega, ncols, 0, nullptr, oc, nullptr);
   }
-  return zk_ntt_ex(ctx, d_a, col_stride, d_a, col_stride, log_n, omega, ncols, 0, nullptr, nullptr);
+  return zk_ntt_ex(ctx, d_a, col_stride, d_a, col_stride, log_n, omega, ncols, 0, nullptr, nullptr, nullptr);
 }

@@ -18,6 +18,7 @@
 #include <string.h>
 
 #include "plonk_kernels.hpp"
+#include "fp29.cuh"
 
 using namespace bn254;
 
@@ -46,7 +47,10 @@ __device__ __forceinline__ bool op_reads_col(uint32_t op) {
   return op == OP_PUSH_COL || op == OP_MUL_COL || op == OP_ADD_COL || op == OP_SUB_COL;
 }
 
+template <bool R261>
 __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_kernel(ExprArgs a) {
+  // the one place the two radices differ: the product (sums, differences, negation act on canonical values)
+  auto fmul = [](const Fr& x, const Fr& y) -> Fr { return R261 ? fr29_mul_rr(x, y) : mul(x, y); };
   extern __shared__ uint4 lds_raw[];
   Fr* stack = reinterpret_cast<Fr*>(lds_raw);  // [depth][EXPR_THREADS]
   const uint32_t tid = threadIdx.x;
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_kernel(ExprArgs a) {
         sp++;
         break;
       case OP_MUL_COL:
-        tos = mul(tos, v);
+        tos = fmul(tos, v);
         break;
       case OP_ADD_COL:
         tos = add(tos, v);
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_kernel(ExprArgs a) {
         sp++;
         break;
       case OP_MUL_HOT:
-        tos = mul(tos, arg == 0 ? hot[0] : arg == 1 ? hot[1] : arg == 2 ? hot[2] : hot[3]);
+        tos = fmul(tos, arg == 0 ? hot[0] : arg == 1 ? hot[1] : arg == 2 ? hot[2] : hot[3]);
         break;
       case OP_PUSH_CONST:
         if (sp > 0) stack[(sp - 1) * EXPR_THREADS + tid] = tos;
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_kernel(ExprArgs a) {
         sp++;
         break;
       case OP_MUL_CONST:
-        tos = mul(tos, ld_fr(cur.ptr));
+        tos = fmul(tos, ld_fr(cur.ptr));
         break;
       case OP_ADD_CONST:
         tos = add(tos, ld_fr(cur.ptr));
@@ -117,17 +121,17 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_kernel(ExprArgs a) {
         sp--;
         break;
       case OP_MUL:
-        tos = mul(stack[(sp - 2) * EXPR_THREADS + tid], tos);
+        tos = fmul(stack[(sp - 2) * EXPR_THREADS + tid], tos);
         sp--;
         break;
       case OP_NEG:
         tos = neg(tos);
         break;
       case OP_SQR:
-        tos = sqr(tos);
+        tos = fmul(tos, tos);
         break;
       case OP_ACC:  // h = h*y + value
-        h = add(mul(h, yv), tos);
+        h = add(fmul(h, yv), tos);
         sp--;
         if (sp > 0) tos = stack[(sp - 1) * EXPR_THREADS + tid];
         break;
@@ -503,8 +507,14 @@ __global__ void scatter_rows_kernel(Fr* dst, size_t col_stride, size_t row0, con
 // ------------------------------------------------------------------------------ launch wrappers
 int zk_expr_eval(amdzk_ctx* ctx, const ExprArgs& a, uint32_t depth, const char* name) {
   size_t shmem = (size_t)(depth ? depth : 1) * EXPR_THREADS * sizeof(Fr);
-  if (shmem > 65536) ZK_HIP(ctx, hipFuncSetAttribute((const void*)expr_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  ZK_LAUNCH(ctx, name, expr_eval_kernel, dim3((unsigned)((a.nrows + EXPR_THREADS - 1) / EXPR_THREADS)), dim3(EXPR_THREADS), shmem, a);
+  const dim3 grid((unsigned)((a.nrows + EXPR_THREADS - 1) / EXPR_THREADS)), block(EXPR_THREADS);
+  if (a.radix261) {
+    if (shmem > 65536) ZK_HIP(ctx, hipFuncSetAttribute((const void*)expr_eval_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    ZK_LAUNCH(ctx, name, expr_eval_kernel<true>, grid, block, shmem, a);
+  } else {
+    if (shmem > 65536) ZK_HIP(ctx, hipFuncSetAttribute((const void*)expr_eval_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    ZK_LAUNCH(ctx, name, expr_eval_kernel<false>, grid, block, shmem, a);
+  }
   return AMDZK_OK;
 }
 

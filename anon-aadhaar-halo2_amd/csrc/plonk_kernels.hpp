@@ -47,6 +47,10 @@ struct ExprArgs {
   size_t nrows;
   const bn254::Fr* y_ptr;        // y (OP_ACC)
   uint32_t hot[EXPR_HOT];        // column slots held in registers for the whole row (rotation 0), or EXPR_NO_SLOT
+  // 0: columns, constants and results are in halo2curves' radix-2^256 Montgomery form (bn254.cuh product).
+  // 1: everything the program touches is in radix 2^261 (32 x the value in the ordinary form): products use
+  //    fp29.cuh's in-place 29-bit product. The prover runs the h(X) program this way (extended domain only).
+  uint32_t radix261;
 };
 
 int zk_expr_eval(amdzk_ctx* ctx, const ExprArgs& a, uint32_t depth, const char* name);

@@ -14,7 +14,7 @@
 using namespace bn254;
 
 int zk_ntt_ex(amdzk_ctx* ctx, const Fr* d_in, size_t in_stride, Fr* d_out, size_t out_stride, uint32_t log_n,
-              const uint64_t omega[4], size_t ncols, uint32_t in_len, const Fr* in_coset, const Fr* out_mul);
+              const uint64_t omega[4], size_t ncols, uint32_t in_len, const Fr* in_coset, const Fr* out_mul, const Fr* in_first);
 Fr zk_fr_inv_pow2(uint32_t log_n);
 
 struct amdzk_domain {
@@ -164,12 +164,12 @@ uint32_t amdzk_domain_extended_k(const amdzk_domain* d) { return d ? d->extended
 int amdzk_lagrange_to_coeff_dev(amdzk_ctx* ctx, const amdzk_domain* d, void* d_cols, size_t ncols, size_t col_stride) {
   if (!ctx || !d || !d_cols) return AMDZK_E_INVALID;
   Fr oc[3] = {d->ifft_divisor, d->ifft_divisor, d->ifft_divisor};
-  return zk_ntt_ex(ctx, (Fr*)d_cols, col_stride, (Fr*)d_cols, col_stride, d->k, (const uint64_t*)d->omega_inv.l, ncols, 0, nullptr, oc);
+  return zk_ntt_ex(ctx, (Fr*)d_cols, col_stride, (Fr*)d_cols, col_stride, d->k, (const uint64_t*)d->omega_inv.l, ncols, 0, nullptr, oc, nullptr);
 }
 
 int amdzk_coeff_to_lagrange_dev(amdzk_ctx* ctx, const amdzk_domain* d, void* d_cols, size_t ncols, size_t col_stride) {
   if (!ctx || !d || !d_cols) return AMDZK_E_INVALID;
-  return zk_ntt_ex(ctx, (Fr*)d_cols, col_stride, (Fr*)d_cols, col_stride, d->k, (const uint64_t*)d->omega.l, ncols, 0, nullptr, nullptr);
+  return zk_ntt_ex(ctx, (Fr*)d_cols, col_stride, (Fr*)d_cols, col_stride, d->k, (const uint64_t*)d->omega.l, ncols, 0, nullptr, nullptr, nullptr);
 }
 
 int amdzk_coeff_to_extended_dev(amdzk_ctx* ctx, const amdzk_domain* d, const void* d_coeff, size_t in_stride,
@@ -177,7 +177,32 @@ int amdzk_coeff_to_extended_dev(amdzk_ctx* ctx, const amdzk_domain* d, const voi
   if (!ctx || !d || !d_coeff || !d_ext) return AMDZK_E_INVALID;
   Fr ic[2] = {d->g_coset, d->g_coset_inv};
   return zk_ntt_ex(ctx, (const Fr*)d_coeff, in_stride, (Fr*)d_ext, out_stride, d->extended_k,
-                   (const uint64_t*)d->extended_omega.l, ncols, 1u << d->k, ic, nullptr);
+                   (const uint64_t*)d->extended_omega.l, ncols, 1u << d->k, ic, nullptr, nullptr);
+}
+
+// The prover's private flavour of the two conversions. The h(X) interpreter multiplies data by data with
+// fp29.cuh's in-place product, which is closed only on radix-2^261 Montgomery values; x*2^261 is the same
+// 32 bytes as (32 x)*2^256, so "extended-domain data in radix 2^261" is simply 32 times the polynomial in
+// the ordinary form — a factor the (linear) transform picks up from its input constants for free, and
+// drops again through its output constants on the way back. The public amdzk_* entry points above are
+// unchanged.
+static Fr fr_k32() {
+  Fr k = Fr::one();
+  for (int i = 0; i < 5; i++) k = add(k, k);
+  return k;
+}
+int zk_coeff_to_extended_r261(amdzk_ctx* ctx, const amdzk_domain* d, const Fr* d_coeff, size_t in_stride, Fr* d_ext, size_t out_stride,
+                              size_t ncols) {
+  const Fr k32 = fr_k32();
+  Fr ic[2] = {mul(d->g_coset, k32), mul(d->g_coset_inv, k32)};
+  return zk_ntt_ex(ctx, d_coeff, in_stride, d_ext, out_stride, d->extended_k, (const uint64_t*)d->extended_omega.l, ncols, 1u << d->k, ic,
+                   nullptr, &k32);
+}
+int zk_extended_to_coeff_from_r261(amdzk_ctx* ctx, const amdzk_domain* d, Fr* d_ext, size_t ncols, size_t col_stride) {
+  const Fr div = mul(d->extended_ifft_divisor, inv(fr_k32()));
+  Fr oc[3] = {div, mul(div, d->g_coset_inv), mul(div, d->g_coset)};
+  return zk_ntt_ex(ctx, d_ext, col_stride, d_ext, col_stride, d->extended_k, (const uint64_t*)d->extended_omega_inv.l, ncols, 0, nullptr, oc,
+                   nullptr);
 }
 
 int amdzk_extended_to_coeff_dev(amdzk_ctx* ctx, const amdzk_domain* d, void* d_ext, size_t ncols, size_t col_stride) {
@@ -185,7 +210,7 @@ int amdzk_extended_to_coeff_dev(amdzk_ctx* ctx, const amdzk_domain* d, void* d_e
   // ifft divisor and the inverse coset powers [1, zeta^-1 = zeta^2, zeta^-2 = zeta] in one multiplier
   Fr oc[3] = {d->extended_ifft_divisor, mul(d->extended_ifft_divisor, d->g_coset_inv), mul(d->extended_ifft_divisor, d->g_coset)};
   return zk_ntt_ex(ctx, (Fr*)d_ext, col_stride, (Fr*)d_ext, col_stride, d->extended_k,
-                   (const uint64_t*)d->extended_omega_inv.l, ncols, 0, nullptr, oc);
+                   (const uint64_t*)d->extended_omega_inv.l, ncols, 0, nullptr, oc, nullptr);
 }
 
 int amdzk_divide_by_vanishing_dev(amdzk_ctx* ctx, const amdzk_domain* d, void* d_ext, size_t ncols, size_t col_stride) {

@@ -45,6 +45,10 @@ int amdzk_coeff_to_extended_dev(amdzk_ctx* ctx, const amdzk_domain* d, const voi
                                 size_t ncols);
 int amdzk_extended_to_coeff_dev(amdzk_ctx* ctx, const amdzk_domain* d, void* d_ext, size_t ncols, size_t col_stride);
 int amdzk_divide_by_vanishing_dev(amdzk_ctx* ctx, const amdzk_domain* d, void* d_ext, size_t ncols, size_t col_stride);
+// prover-private: extended-domain data in Montgomery radix 2^261 (poly.hip) — what the h(X) program multiplies in
+int zk_coeff_to_extended_r261(amdzk_ctx* ctx, const amdzk_domain* d, const Fr* d_coeff, size_t in_stride, Fr* d_ext, size_t out_stride,
+                              size_t ncols);
+int zk_extended_to_coeff_from_r261(amdzk_ctx* ctx, const amdzk_domain* d, Fr* d_ext, size_t ncols, size_t col_stride);
 int amdzk_fr_to_repr_dev(amdzk_ctx* ctx, void* d_a, size_t n);
 int amdzk_fr_from_raw_dev(amdzk_ctx* ctx, void* d_a, size_t n);
 }
@@ -153,6 +157,7 @@ struct amdzk_pk {
   Program prog_compress, prog_pfrac, prog_lfrac, prog_h;
   RotTable rots;
   Fr* d_consts = nullptr;
+  Fr* d_consts261 = nullptr;  // the same table times 32 (= radix 2^261): constants of programs run on the extended domain
   const Fr** d_cols_lag = nullptr;
   const Fr** d_cols_ext = nullptr;
   Fr** d_outs_compress = nullptr;
@@ -403,6 +408,18 @@ int emit_compressed(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, uint32_t first, u
   return AMDZK_OK;
 }
 
+// d_consts261[i] = 32 * consts[i] in the ordinary form, i.e. consts[i] in radix 2^261 (a few hundred values).
+int upload_consts261(amdzk_ctx* ctx, amdzk_pk* pk) {
+  Fr k32 = Fr::one();
+  for (int i = 0; i < 5; i++) k32 = add(k32, k32);
+  std::vector<Fr> c(pk->consts.size());
+  for (size_t i = 0; i < c.size(); i++) c[i] = mul(pk->consts[i], k32);
+  ZK_TRY(h2d_staged(ctx, pk, pk->d_consts261, c.data(), c.size() * 32));
+  // without the pinned staging area the copy above reads `c` asynchronously: finish it before `c` goes away
+  if (!pk->pin || c.size() * 32 > pk->pin_cap) ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AMDZK_OK;
+}
+
 // Resolve slots / rotation indices / constant indices into addresses and row offsets for one domain
 // and upload the 16-byte instructions.
 int upload_program(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, bool extended) {
@@ -420,7 +437,7 @@ int upload_program(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, bool extended) {
       ins[i].rot = pk->rots.rots[arg & 0xff] * scale;
     } else if (op == OP_PUSH_CONST || op == OP_MUL_CONST || op == OP_ADD_CONST) {
       if (arg >= pk->consts.size()) ZK_FAIL(ctx, AMDZK_E_INVALID, "program: bad constant operand");
-      ins[i].ptr = pk->d_consts + arg;
+      ins[i].ptr = (extended ? pk->d_consts261 : pk->d_consts) + arg;
     }
   }
   ZK_TRY(dalloc(ctx, pk, &pr.d_instr, ins.size()));
@@ -438,7 +455,11 @@ int run_program(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, bool extended, Fr* co
   a.h_out = h_out;
   a.nrows = extended ? pk->ext : pk->n;
   a.mask = a.nrows - 1;
-  a.y_ptr = pk->d_consts + pk->c_y;
+  // Extended-domain programs (h(X), l_active) run in radix 2^261: their columns come from
+  // zk_coeff_to_extended_r261, their constants from d_consts261, and the result goes back through
+  // zk_extended_to_coeff_from_r261. Lagrange-domain programs read the caller's radix-2^256 witness as is.
+  a.radix261 = extended ? 1u : 0u;
+  a.y_ptr = (extended ? pk->d_consts261 : pk->d_consts) + pk->c_y;
   for (int i = 0; i < EXPR_HOT; i++) a.hot[i] = EXPR_NO_SLOT;
   if (extended && pr.uses_hot) {
     a.hot[0] = pk->se_l0();
@@ -643,11 +664,12 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
     for (int t = 0; t < 3; t++) {
       KG_TRY(h2d(ctx, tmp, src[t]->data(), n * 32));
       KG_TRY(amdzk_lagrange_to_coeff_dev(ctx, pk->dom, tmp, 1, n));
-      KG_TRY(amdzk_coeff_to_extended_dev(ctx, pk->dom, tmp, n, dst[t], ext, 1));
+      KG_TRY(zk_coeff_to_extended_r261(ctx, pk->dom, tmp, n, dst[t], ext, 1));
       ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     std::vector<Fr> xc(ext);
     cur = zeta;
+    for (int i = 0; i < 5; i++) cur = add(cur, cur);  // 32 * zeta * omega_ext^i: the coset points in radix 2^261
     for (size_t i = 0; i < ext; i++) {
       xc[i] = cur;
       cur = mul(cur, ext_omega);
@@ -664,7 +686,7 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
     KG_TRY(h2d(ctx, pk->fixed_lag, fixed_values, (size_t)F * n * 32));
     KG_TRY(d2d(ctx, pk->fixed_poly, pk->fixed_lag, (size_t)F * n * 32));
     KG_TRY(amdzk_lagrange_to_coeff_dev(ctx, pk->dom, pk->fixed_poly, F, n));
-    KG_TRY(amdzk_coeff_to_extended_dev(ctx, pk->dom, pk->fixed_poly, n, pk->fixed_coset, ext, F));
+    KG_TRY(zk_coeff_to_extended_r261(ctx, pk->dom, pk->fixed_poly, n, pk->fixed_coset, ext, F));
     KG_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G_LAGRANGE, pk->fixed_lag, F, pk->fixed_commitments));
   }
   if (S) {
@@ -697,7 +719,7 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     KG_TRY(d2d(ctx, pk->sigma_poly, pk->sigma_lag, (size_t)S * n * 32));
     KG_TRY(amdzk_lagrange_to_coeff_dev(ctx, pk->dom, pk->sigma_poly, S, n));
-    KG_TRY(amdzk_coeff_to_extended_dev(ctx, pk->dom, pk->sigma_poly, n, pk->sigma_coset, ext, S));
+    KG_TRY(zk_coeff_to_extended_r261(ctx, pk->dom, pk->sigma_poly, n, pk->sigma_coset, ext, S));
     KG_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G_LAGRANGE, pk->sigma_lag, S, pk->perm_commitments));
   }
   // l_active = 1 - (l_last + l_blind) on the coset: lactive_c currently holds l_blind's coset
@@ -936,6 +958,7 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
   }
   KG_TRY(dalloc(ctx, pk, &pk->d_consts, pk->consts.size()));
   KG_TRY(h2d(ctx, pk->d_consts, pk->consts.data(), pk->consts.size() * 32));
+  KG_TRY(dalloc(ctx, pk, &pk->d_consts261, pk->consts.size()));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   KG_TRY(upload_program(ctx, pk, pk->prog_compress, false));
   KG_TRY(upload_program(ctx, pk, pk->prog_pfrac, false));
@@ -943,6 +966,8 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
   KG_TRY(upload_program(ctx, pk, pk->prog_h, true));
   // l_active coset = 1 - (l_last + l_blind): lactive_c holds l_blind's coset; tiny one-off program
   {
+    KG_TRY(upload_consts261(ctx, pk));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     Program pr;
     pr.op(OP_PUSH_CONST, pk->c_one); pr.push();
     pr.op(OP_SUB_COL, COL(pk->se_llast(), r0));
@@ -1237,11 +1262,12 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
   ZK_TRY(h2d_staged(ctx, pk, pk->d_consts + pk->c_y, &pk->consts[pk->c_y], 32));
   // 6. every committed column: Lagrange -> coefficients -> extended coset; then h(X)
   ZK_TRY(amdzk_lagrange_to_coeff_dev(ctx, pk->dom, pk->P, pk->NP, n));
-  ZK_TRY(amdzk_coeff_to_extended_dev(ctx, pk->dom, pk->P, n, pk->PC, ext, pk->NP));
+  ZK_TRY(zk_coeff_to_extended_r261(ctx, pk->dom, pk->P, n, pk->PC, ext, pk->NP));
+  ZK_TRY(upload_consts261(ctx, pk));  // theta, beta, gamma, delta powers, y are all known by now
   tick("intt+coset_ntt");
   ZK_TRY(run_program(ctx, pk, pk->prog_h, true, nullptr, pk->hq, "expr_evaluate_h"));
   ZK_TRY(amdzk_divide_by_vanishing_dev(ctx, pk->dom, pk->hq, 1, ext));
-  ZK_TRY(amdzk_extended_to_coeff_dev(ctx, pk->dom, pk->hq, 1, ext));
+  ZK_TRY(zk_extended_to_coeff_from_r261(ctx, pk->dom, pk->hq, 1, ext));
   {
     for (uint32_t i = 0; i < pk->qdeg; i++) (void)rng.fr();  // h_blinds
     std::vector<G1Affine> cm;
