@@ -254,7 +254,7 @@ def main():
                 else "create_proof wall-clock (ms) + proofs/sec, RSA-SHA256 circuit shape",
                 "value": round(world * args.steps / dt, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "u32x8 (254-bit Montgomery integers)", "data": "synthetic",
+                "vs_baseline": None, "dtype": "u32 limbs (254-bit Montgomery integers: 9 x 29-bit in the hot products, 8 x 32-bit elsewhere)", "data": "synthetic",
                 "config": {"workload": "create_proof, %s %s: %d advice, %d lookups, %d permutation columns, degree %d, "
                                        "KZG/SHPLONK/Blake2b, witness resident"
                                        % (make_circuit.__name__, args.shape, desc["num_advice"], len(desc["lookups"]), len(desc["permutation_columns"]), desc["cs_degree"]),
