@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256) void poly_eval_kernel(const Fr* const* polys, 
   if (t < n) {
     uint32_t top = (n - 1 - t) / 256;  // largest j with t + 256 j < n
     s = ld_fr(p + t + 256u * top);
-    for (uint32_t j = top; j-- > 0;) s = add(mul(s, x256), ld_fr(p + t + 256u * j));
+    const Fr x256r = fr29_const_to_r261(x256);  // the Horner multiplier, radix 2^261 (mixed-radix product)
+    for (uint32_t j = top; j-- > 0;) s = add(fr29_mul_const(s, x256r), ld_fr(p + t + 256u * j));
     s = mul(s, pow_u64(x, t));
   }
   red[t] = s;
@@ -278,16 +279,31 @@ __global__ __launch_bounds__(256) void poly_eval_kernel(const Fr* const* polys, 
 
 // ------------------------------------------------------------------------------ linear combinations
 // out[i] = (accumulate ? out[i] : 0) + sum_j coefs[j] * polys[j][i]
+// out[i] (+)= sum_j coefs[j] * polys[j][i]. Data x constant: the coefficients are converted once per workgroup
+// to radix 2^261 (fp29.cuh, "mixed radix") and staged in LDS, LC_CHUNK at a time; every term is then one
+// in-place 29-bit product on data that stays in the ordinary form.
+constexpr uint32_t LC_CHUNK = 256;
 __global__ __launch_bounds__(256) void lincomb_kernel(const Fr* const* polys, const Fr* coefs, uint32_t m, Fr* out, size_t n,
                                                       int accumulate) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    Fr acc = accumulate ? ld_fr(out + i) : Fr::zero();
-    for (uint32_t j = 0; j < m; j++) acc = add(acc, mul(ld_fr(coefs + j), ld_fr(polys[j] + i)));
-    st_fr(out + i, acc);
+  __shared__ Fr c261[LC_CHUNK];
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // every thread of the block walks the same number of rounds, so the barriers below are uniform
+  const size_t rounds = n > (size_t)blockIdx.x * blockDim.x ? (n - (size_t)blockIdx.x * blockDim.x + stride - 1) / stride : 0;
+  for (uint32_t j0 = 0; j0 < m; j0 += LC_CHUNK) {
+    const uint32_t jn = min(LC_CHUNK, m - j0);
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < jn; j += blockDim.x) c261[j] = fr29_const_to_r261(ld_fr(coefs + j0 + j));
+    __syncthreads();
+    for (size_t r = 0; r < rounds; r++) {
+      const size_t i = first + r * stride;
+      if (i >= n) continue;
+      Fr acc = (accumulate || j0 != 0) ? ld_fr(out + i) : Fr::zero();
+      for (uint32_t j = 0; j < jn; j++) acc = add(acc, fr29_mul_const(ld_fr(polys[j0 + j] + i), c261[j]));
+      st_fr(out + i, acc);
+    }
   }
 }
-
-// a[i] = a[i] * c
 __global__ __launch_bounds__(256) void scale_kernel(Fr* a, size_t n, Fr c) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     st_fr(a + i, mul(ld_fr(a + i), c));
@@ -315,11 +331,12 @@ __global__ __launch_bounds__(KD_THREADS) void kate_div_kernel(Fr* const* polys, 
   const uint32_t t = threadIdx.x, blk = blockIdx.x, poly = blockIdx.y;
   Fr* a = polys[poly];
   const Fr b = ld_fr(roots + poly);
+  const Fr br = fr29_const_to_r261(b);  // the root in radix 2^261: the chunk recurrences are data x constant
   const uint32_t s = blk * KD_BLOCK + t * KD_E, e = min(s + KD_E, n);
   Fr acc = Fr::zero();
   if (s < n) {
     acc = ld_fr(a + e - 1);
-    for (uint32_t j = e - 1; j-- > s;) acc = add(mul(acc, b), ld_fr(a + j));
+    for (uint32_t j = e - 1; j-- > s;) acc = add(fr29_mul_const(acc, br), ld_fr(a + j));
   }
   S[t] = acc;  // chunk value relative to its own start
   __syncthreads();
@@ -342,7 +359,7 @@ __global__ __launch_bounds__(KD_THREADS) void kate_div_kernel(Fr* const* polys, 
     for (uint32_t j = e; j-- > s;) {
       Fr aj = ld_fr(a + j);
       st_fr(a + j, prev);
-      prev = add(aj, mul(b, prev));
+      prev = add(aj, fr29_mul_const(prev, br));
     }
   }
 }
@@ -559,6 +576,10 @@ int zk_poly_eval(amdzk_ctx* ctx, const Fr* const* d_polys, const Fr* d_points, F
 }
 
 int zk_lincomb(amdzk_ctx* ctx, const Fr* const* d_polys, const Fr* d_coefs, uint32_t m, Fr* d_out, size_t n, bool accumulate) {
+  if (m == 0) {  // the empty sum
+    if (!accumulate && n) ZK_HIP(ctx, hipMemsetAsync(d_out, 0, n * sizeof(Fr), ctx->stream));
+    return AMDZK_OK;
+  }
   unsigned gx = (unsigned)((n + 255) / 256);
   if (gx > 2048) gx = 2048;
   ZK_LAUNCH(ctx, "lincomb", lincomb_kernel, dim3(gx), dim3(256), 0, d_polys, d_coefs, m, d_out, n, accumulate ? 1 : 0);
