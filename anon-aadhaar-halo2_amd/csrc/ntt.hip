@@ -81,24 +81,43 @@ __device__ __forceinline__ Fr tw_lookup(const Fr* tw, uint32_t e, uint32_t log_n
   return (e & half) ? neg(w) : w;
 }
 
+// The tile lives in LDS as 9 x 29-bit limbs (36 B per element; the odd word stride is bank-conflict free),
+// not as packed 32-byte values: a butterfly is then a lazy limb-wise sum, a difference plus 10p, and ONE
+// in-place product — no unpack/pack and no carry-chain add around it. Bounds, in units of p: elements
+// enter below 2 (canonical, or a coset product); a sum doubles the bound, a twiddle product resets it
+// below 2; every third round the sums are brought back below 2 with f29_reduce_weak (~30 instructions), so
+// no element exceeds 16.8 and every subtrahend stays below 9 (the range f29_sub10 covers). Elements are
+// packed to canonical 32-byte values only when they leave the tile.
+__device__ __forceinline__ Fr29 lds_ld(const uint32_t* L, uint32_t e) {
+  Fr29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = L[e * 9 + i];
+  return r;
+}
+__device__ __forceinline__ void lds_st(uint32_t* L, uint32_t e, const Fr29& v) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) L[e * 9 + i] = v.l[i];
+}
+__device__ __forceinline__ Fr pack_out(const Fr29& v_below_2p) { return f29_pack_canonical<FrP>(v_below_2p); }
+
 template <bool LAST>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
   extern __shared__ uint4 lds_raw[];
-  Fr* L = reinterpret_cast<Fr*>(lds_raw);
+  uint32_t* L = reinterpret_cast<uint32_t*>(lds_raw);
   const uint32_t tid = threadIdx.x;
   const uint32_t C = 1u << a.log_c;
   const uint32_t rows = 1u << a.s;
   const uint32_t tile = rows << a.log_c;
-  Fr* TW = L + tile;  // rows/2 sub-transform twiddles omega_{n_p}^i
+  uint32_t* TW = L + (size_t)tile * 9;  // rows/2 sub-transform twiddles omega_{n_p}^i (radix 2^261), as limbs
   const uint32_t tile_id = blockIdx.x;
   const Fr* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
   Fr* out = a.out + (size_t)blockIdx.y * a.out_col_stride;
   const uint32_t log_n = a.log_n;
 
   // ---- stage the sub-transform twiddles: omega_{n_p}^i = omega^(i * n/n_p)
-  for (uint32_t i = tid; i < (rows >> 1); i += NTT_THREADS) TW[i] = ld_fr(a.tw + ((size_t)i << (log_n - a.s)));
+  for (uint32_t i = tid; i < (rows >> 1); i += NTT_THREADS) lds_st(TW, i, fr29_unpack(ld_fr(a.tw + ((size_t)i << (log_n - a.s)))));
 
-  // ---- load the tile
+  // ---- load the tile (whole elements; consecutive lanes read consecutive elements of a contiguous run)
   size_t in_base, row_stride;
   uint32_t hi = 0, lo_base = 0, j2 = 0, j1_blk = 0;
   if (!LAST) {
@@ -107,14 +126,13 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
     lo_base = (tile_id & ((1u << log_lo_blocks) - 1)) << a.log_c;
     in_base = ((size_t)hi << (a.s + a.log_stride)) + lo_base;
     row_stride = (size_t)1 << a.log_stride;
-    // element (x, c) at in_base + x*row_stride + c ; 16-byte pieces, c fastest
-    const uint32_t pieces = tile * 2, ppr = C * 2;
-    for (uint32_t q = tid; q < pieces; q += NTT_THREADS) {
-      uint32_t x = q / ppr, c2 = q % ppr;
-      size_t gi = in_base + (size_t)x * row_stride + (c2 >> 1);
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (a.pass != 0 || gi < a.in_len) v = reinterpret_cast<const uint4*>(in + gi)[c2 & 1];
-      lds_raw[q] = v;
+    // element (x, c) at in_base + x*row_stride + c, LDS index x*C + c
+    for (uint32_t e = tid; e < tile; e += NTT_THREADS) {
+      const uint32_t x = e >> a.log_c, c = e & (C - 1);
+      const size_t gi = in_base + (size_t)x * row_stride + c;
+      Fr v = Fr::zero();
+      if (a.pass != 0 || gi < a.in_len) v = ld_fr(in + gi);
+      lds_st(L, e, fr29_unpack(v));
     }
   } else {
     // rows of the tile are C consecutive values of j1 (the fastest output digit)
@@ -126,49 +144,54 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
     }
     row_stride = a.npass == 1 ? 0 : ((size_t)1 << (log_n - a.log_n1));
     in_base = (size_t)(j1_blk << a.log_c) * row_stride + (a.npass == 3 ? ((size_t)j2 << a.s) : 0);
-    const uint32_t pieces = tile * 2, ppr = rows * 2;
-    for (uint32_t q = tid; q < pieces; q += NTT_THREADS) {
-      uint32_t rr = q / ppr, x2 = q % ppr;
-      size_t gi = in_base + (size_t)rr * row_stride + (x2 >> 1);
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (a.pass != 0 || gi < a.in_len) v = reinterpret_cast<const uint4*>(in + gi)[x2 & 1];
-      lds_raw[((((x2 >> 1) << a.log_c) + rr) << 1) + (x2 & 1)] = v;
+    // element (rr, x) at in_base + rr*row_stride + x, LDS index x*C + rr
+    for (uint32_t q = tid; q < tile; q += NTT_THREADS) {
+      const uint32_t rr = q >> a.s, x = q & (rows - 1);
+      const size_t gi = in_base + (size_t)rr * row_stride + x;
+      Fr v = Fr::zero();
+      if (a.pass != 0 || gi < a.in_len) v = ld_fr(in + gi);
+      lds_st(L, (x << a.log_c) + rr, fr29_unpack(v));
     }
   }
   __syncthreads();
 
   // ---- first step only: move into the coset (distribute_powers_zeta) — whole elements
   if (a.pass == 0 && (a.flags & F_IN_COSET)) {
+    const Fr29 c1 = fr29_unpack(a.in_c[0]), c2 = fr29_unpack(a.in_c[1]), c0 = fr29_unpack(a.in_c0);
     for (uint32_t e = tid; e < tile; e += NTT_THREADS) {
       uint32_t x = e >> a.log_c, c = e & (C - 1);
       size_t gi = LAST ? (in_base + (size_t)c * row_stride + x) : (in_base + (size_t)x * row_stride + c);
       uint32_t m = (uint32_t)(gi % 3);
       if (gi < a.in_len) {
-        if (m != 0) L[e] = fr29_mul_const(L[e], a.in_c[m - 1]);
-        else if (a.flags & F_IN_ALL) L[e] = fr29_mul_const(L[e], a.in_c0);
+        if (m != 0) lds_st(L, e, f29_mul(lds_ld(L, e), m == 1 ? c1 : c2));
+        else if (a.flags & F_IN_ALL) lds_st(L, e, f29_mul(lds_ld(L, e), c0));
       }
     }
     __syncthreads();
   }
 
   // ---- radix-2 DIF rounds over the row dimension; result row r holds output index brev(r)
-  for (int st = (int)a.s - 1; st >= 0; --st) {
+  uint32_t round = 0;
+  for (int st = (int)a.s - 1; st >= 0; --st, ++round) {
     const uint32_t h = 1u << st;
+    const bool reduce_sums = (round % 3) == 2;
     for (uint32_t b = tid; b < (tile >> 1); b += NTT_THREADS) {
       uint32_t c = b & (C - 1), m = b >> a.log_c;
       uint32_t i = m & (h - 1), blk = m >> st;
       uint32_t x0 = (blk << (st + 1)) + i;
       uint32_t e0 = (x0 << a.log_c) + c, e1 = ((x0 + h) << a.log_c) + c;
-      Fr u = L[e0], v = L[e1];
-      L[e0] = add(u, v);
-      Fr d = sub(u, v);
-      if (st > 0) d = fr29_mul_const(d, TW[i << (a.s - 1 - st)]);
-      L[e1] = d;
+      Fr29 u = lds_ld(L, e0), v = lds_ld(L, e1);
+      Fr29 sum = f29_add(u, v);
+      if (reduce_sums) sum = f29_reduce_weak(sum);
+      lds_st(L, e0, sum);
+      Fr29 d = f29_sub10(u, v);  // below bound(u) + 10
+      if (st > 0) d = f29_mul(d, lds_ld(TW, i << (a.s - 1 - st)));
+      lds_st(L, e1, d);
     }
     __syncthreads();
   }
 
-  // ---- store
+  // ---- store: every element leaves through a product (below 2p) or a weak reduction, then is packed
   if (!LAST) {
     // twiddle omega^(g * i_next * (J_prev + N_prev*j)),  g = n / N_{p+1}
     const uint32_t J_prev = hi;  // step 0: hi = 0; step 1 of 3: hi = j1
@@ -176,22 +199,28 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
     const uint32_t sh_next = a.log_stride - a.log_next;
     for (uint32_t e = tid; e < tile; e += NTT_THREADS) {
       uint32_t j = e >> a.log_c, c = e & (C - 1);
-      Fr x = L[(brev(j, a.s) << a.log_c) + c];
+      Fr29 x = lds_ld(L, (brev(j, a.s) << a.log_c) + c);
       uint32_t i_next = (lo_base + c) >> sh_next;
       uint32_t Jp = J_prev + (j << a.log_prev);
       uint32_t ex = (i_next * Jp) << log_g;
-      if (ex != 0) x = fr29_mul_const(x, tw_lookup(a.tw, ex, log_n));
-      st_fr(out + in_base + (size_t)j * row_stride + c, x);
+      x = ex != 0 ? f29_mul(x, fr29_unpack(tw_lookup(a.tw, ex, log_n))) : f29_reduce_weak(x);
+      st_fr(out + in_base + (size_t)j * row_stride + c, pack_out(x));
     }
   } else {
     const size_t out_base = (size_t)(j1_blk << a.log_c) + (a.npass == 3 ? ((size_t)j2 << a.log_n1) : 0);
     const uint32_t log_ostride = log_n - a.s;  // N_{P-1}
+    const Fr29 oc0 = fr29_unpack(a.out_c[0]), oc1 = fr29_unpack(a.out_c[1]), oc2 = fr29_unpack(a.out_c[2]);
     for (uint32_t e = tid; e < tile; e += NTT_THREADS) {
       uint32_t j = e >> a.log_c, rr = e & (C - 1);
-      Fr x = L[(brev(j, a.s) << a.log_c) + rr];
+      Fr29 x = lds_ld(L, (brev(j, a.s) << a.log_c) + rr);
       size_t oi = out_base + rr + ((size_t)j << log_ostride);
-      if (a.flags & F_OUT_MUL) x = fr29_mul_const(x, a.out_c[oi % 3]);
-      st_fr(out + oi, x);
+      if (a.flags & F_OUT_MUL) {
+        const uint32_t m = (uint32_t)(oi % 3);
+        x = f29_mul(x, m == 0 ? oc0 : m == 1 ? oc1 : oc2);
+      } else {
+        x = f29_reduce_weak(x);
+      }
+      st_fr(out + oi, pack_out(x));
     }
   }
 }
@@ -337,7 +366,7 @@ int zk_ntt_ex(amdzk_ctx* ctx, const Fr* d_in, size_t in_stride, Fr* d_out, size_
     a.out_col_stride = last ? out_stride : n;
     const uint32_t tile_elems_log = a.s + a.log_c;
     dim3 grid((uint32_t)(n >> tile_elems_log), (uint32_t)ncols), block(NTT_THREADS);
-    size_t shmem = (((size_t)1 << tile_elems_log) + ((size_t)1 << a.s) / 2 + 1) * sizeof(Fr);
+    size_t shmem = (((size_t)1 << tile_elems_log) + ((size_t)1 << a.s) / 2 + 1) * 9 * sizeof(uint32_t);  // limbs, see ntt_step_kernel
     if (last) {
       if (shmem > 65536) ZK_HIP(ctx, hipFuncSetAttribute((const void*)ntt_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
       ZK_LAUNCH(ctx, "ntt_step_last", ntt_step_kernel<true>, grid, block, shmem, a);

@@ -67,6 +67,50 @@ int main() {
     }
   }
   printf("Fr29 mixed radix ok\n");
+  // --- weak reduction, both fields: any normalised 9-limb value -> same residue, below 2p, normalised
+  {
+    auto check = [&](auto tag, const char* name) {
+      using P = decltype(tag);
+      for (int t = 0; t < 40000; t++) {
+        Fp29<P> v;
+        for (int i = 0; i < 9; i++) v.l[i] = (uint32_t)rnd() & F29_MASK;
+        if (t % 4 == 1) v.l[8] = (uint32_t)(rnd() % 170) * (P::p(8) + 1) + (uint32_t)(rnd() % 5) - 2;  // quotient boundaries
+        if (t % 4 == 2) v.l[8] = (uint32_t)rnd() & 0x3ffffff;                                            // the range the NTT produces
+        if (t == 3) for (int i = 0; i < 9; i++) v.l[i] = F29_MASK;
+        if (t == 7) for (int i = 0; i < 9; i++) v.l[i] = 0;
+        v.l[8] &= F29_MASK;
+        Fp29<P> r = f29_reduce_weak(v);
+        for (int i = 0; i < 8; i++)
+          if (r.l[i] >> 29) { fails++; printf("%s reduce_weak: limb not normalised\n", name); }
+        // below 2p: r - 2p must borrow
+        int64_t acc = 0;
+        for (int i = 0; i < 9; i++) { acc += (int64_t)r.l[i] - 2 * (int64_t)P::p(i); acc >>= 29; }
+        if (acc >= 0) { fails++; printf("%s reduce_weak: result >= 2p\n", name); }
+        // same residue: v * 1 and r * 1 through the product (both operands in range: v < 169p, one < p)
+        Fp29<P> a = f29_mul(v, f29_one<P>()), b = f29_mul(r, f29_one<P>());
+        bool same = true;
+        {
+          // compare canonical forms
+          Fp29<P> ca = f29_reduce_weak(a), cb = f29_reduce_weak(b);
+          auto canon = [](Fp29<P> x) {
+            int64_t bw = 0;
+            Fp29<P> t2;
+            for (int i = 0; i < 9; i++) { int64_t d = (int64_t)x.l[i] - (int64_t)P::p(i) + bw; t2.l[i] = i < 8 ? ((uint32_t)d & F29_MASK) : (uint32_t)d; bw = d >> 29; }
+            return bw < 0 ? x : t2;
+          };
+          ca = canon(ca);
+          cb = canon(cb);
+          for (int i = 0; i < 9; i++) same = same && ca.l[i] == cb.l[i];
+        }
+        if (!same) { fails++; printf("%s reduce_weak: residue changed\n", name); }
+        if (fails > 5) return;
+      }
+    };
+    check(Fr29P{}, "Fr");
+    check(Fq29P{}, "Fq");
+    if (fails) return 1;
+  }
+  printf("weak reduction ok\n");
   // --- points: k*G for small k with the 32-bit code
   G1Affine g;
   g.x = Fq::one();
