@@ -66,6 +66,15 @@ int main() {
       if (memcmp(got_n.l, want_n.l, 32) != 0) { fails++; printf("Fr negated constant\n"); if (fails > 5) return 1; }
     }
   }
+  for (int t = 0; t < 300; t++) {  // inversion chain on the 29-bit product = bn254.cuh's inv
+    Fr x;
+    for (int i = 0; i < 8; i++) x.l[i] = (uint32_t)rnd();
+    x.l[7] &= 0x0fffffffu;
+    if (t == 0) x = Fr::one();
+    if (t == 1) for (int i = 0; i < 8; i++) x.l[i] = FrP::p(i) - (i == 0);  // r - 1
+    Fr got = fr29_inv(x), want = inv(x);
+    if (memcmp(got.l, want.l, 32) != 0) { fails++; printf("fr29_inv\n"); if (fails > 5) return 1; }
+  }
   printf("Fr29 mixed radix ok\n");
   // --- weak reduction, both fields: any normalised 9-limb value -> same residue, below 2p, normalised
   {
