@@ -276,17 +276,17 @@ def main():
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
-    command (profiles/r01t_kernel_summary.csv; counters cannot be read from inside the process).
+    command (profiles/r01v_kernel_summary.csv; counters cannot be read from inside the process).
     FETCH_SIZE + WRITE_SIZE in KiB; the gfx950 x2 FETCH correction is for wide coalesced streams and is
     NOT applied to this kernel's 64-byte random gathers (uncalibrated pattern, stated as such)."""
     names = {"msm_accum_l1": "msm_accum_seg_kernel<true>", "expr_evaluate_h": "expr_eval_kernel"}
-    path = os.path.join(ROOT, "profiles", "r01t_kernel_summary.csv")
+    path = os.path.join(ROOT, "profiles", "r01v_kernel_summary.csv")
     try:
         import csv
         for row in csv.DictReader(open(path)):
             if row["kernel"] == names.get(kernel) and row["FETCH_SIZE_KiB_per_launch_raw"]:
                 b = (float(row["FETCH_SIZE_KiB_per_launch_raw"]) + float(row["WRITE_SIZE_KiB_per_launch_raw"])) * 1024
-                return round(b), "profiles/r01t_kernel_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, raw, per launch)"
+                return round(b), "profiles/r01v_kernel_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, raw, per launch)"
     except OSError:
         pass
     return None, None
