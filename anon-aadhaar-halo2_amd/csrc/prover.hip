@@ -964,6 +964,27 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
   KG_TRY(upload_program(ctx, pk, pk->prog_pfrac, false));
   KG_TRY(upload_program(ctx, pk, pk->prog_lfrac, false));
   KG_TRY(upload_program(ctx, pk, pk->prog_h, true));
+  if (getenv("AMDZK_DUMP_PROG")) {  // debugging aid: what the compiled h(X) program is made of
+    static const char* names[] = {"END", "PUSH_COL", "PUSH_CONST", "ADD", "SUB", "MUL", "NEG", "MUL_CONST", "ADD_CONST", "MUL_COL",
+                                  "ADD_COL", "SUB_COL", "ACC", "STORE", "SQR", "PUSH_HOT", "MUL_HOT"};
+    std::map<uint32_t, size_t> hist;
+    std::map<std::pair<uint32_t, uint32_t>, size_t> pairs;
+    const auto& w = pk->prog_h.words;
+    for (size_t i = 0; i < w.size(); i++) {
+      hist[w[i] >> 24]++;
+      if (i + 1 < w.size()) pairs[{w[i] >> 24, w[i + 1] >> 24}]++;
+    }
+    fprintf(stderr, "[amdzk] prog_h: %zu instructions, stack depth %u\n", w.size(), pk->prog_h.depth);
+    for (auto& kv : hist) fprintf(stderr, "[amdzk]   %-10s %zu\n", kv.first < 17 ? names[kv.first] : "?", kv.second);
+    auto is_mul = [](uint32_t o) { return o == OP_MUL || o == OP_MUL_CONST || o == OP_MUL_COL || o == OP_MUL_HOT || o == OP_SQR || o == OP_ACC; };
+    size_t mm = 0;
+    for (auto& kv : pairs)
+      if (is_mul(kv.first.first) && is_mul(kv.first.second)) {
+        mm += kv.second;
+        fprintf(stderr, "[amdzk]   product -> product: %s -> %s x %zu\n", names[kv.first.first], names[kv.first.second], kv.second);
+      }
+    fprintf(stderr, "[amdzk]   products directly followed by a product: %zu\n", mm);
+  }
   // l_active coset = 1 - (l_last + l_blind): lactive_c holds l_blind's coset; tiny one-off program
   {
     KG_TRY(upload_consts261(ctx, pk));
