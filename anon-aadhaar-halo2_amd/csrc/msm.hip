@@ -18,13 +18,17 @@
 //    skewed witness columns (mostly 0/1/small limbs) and uniform scalars load the chip equally.
 //    Level 1 adds affine points into XYZZ accumulators (8M+2S per add), levels 2-3 fold the
 //    per-task partial sums.
+//  * All of this runs on fp29.cuh's 9 x 29-bit limbs in Montgomery radix 2^261 (in-place 64-bit column
+//    accumulation, lazy reduction: 1.7x the 32-bit product on this chip). The window tables store that
+//    radix, partial sums cross HBM as raw limbs, and only the one result per column is converted back.
 //  * The weighted fold sum_b (b+1)*B_b is done without a serial running sum: with b = r + 64*g,
-//    sum = sum_r r*C_r + sum_g (64g+1)*T_g where C_r / T_g are plain column / row sums, each a
-//    wavefront-wide (64-lane) shuffle-tree reduction.
+//    sum = sum_r r*C_r + 64*sum_g g*T_g + sum_g T_g where C_r / T_g are plain column / row sums
+//    (lane-per-output serial sums: the prover is bound by instruction issue, and a shuffle tree spends six
+//    wave-level additions where a lane loop spends one), then three short reductions per column.
 //  * Many columns over the same bases (all advice columns of a phase) go through every kernel in
 //    one launch: grid.y = column.
 //
-// No MFMA: this is 254-bit modular integer work (v_mad_u64_u32), and it is ALU-bound, not HBM-bound.
+// No MFMA: this is 254-bit modular integer work (v_mad_u64_u32), and it is bound by VALU instruction issue, not by HBM.
 #include <stdlib.h>
 #include <string.h>
 

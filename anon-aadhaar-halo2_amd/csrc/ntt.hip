@@ -16,7 +16,9 @@
 // exists. Arithmetic is exact, so the result is bit-identical to best_fft's.
 //
 // Data stay AoS (32-byte Fr, two 16-byte accesses per lane) — the host format — so Rust slices and
-// device columns share one layout.
+// device columns share one layout. Inside a tile the elements are 9 x 29-bit limbs (fp29.cuh): every
+// multiplication is data x precomputed constant, the constants (twiddles, coset and output factors) are kept
+// in Montgomery radix 2^261, and a butterfly is a lazy sum, a difference and one in-place product.
 #include <stdlib.h>
 #include <string.h>
 
