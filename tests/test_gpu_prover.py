@@ -165,6 +165,43 @@ def test_gwc_multiopen_equals_oracle(ctx, pkg, plonk, oracle):
     d_adv.free(); pk.free(); params.free()
 
 
+def test_concurrent_proofs_on_separate_contexts_equal_sequential_ones(pkg, plonk, oracle):
+    """What bench.py relies on: four contexts (own stream, SRS handle, proving key and workspace each) driven
+    from four host threads at once produce exactly the bytes the same seeds give one at a time — no state
+    is shared between contexts (twiddle caches, workspaces, staging buffers are per context / per key).
+    Checked on the composite shape at k = 9 so that every kernel family of the prover runs concurrently."""
+    import threading
+
+    c = circuits.full_aadhaar_shape(plonk, k=9, num_advice=6, num_lookup_advice=2, lookup_bits=6, num_spread=2, spread_bits=4)
+    ctxs = [pkg.Context(0) for _ in range(4)]
+    keys = [setup(cx, pkg, plonk, oracle, c) for cx in ctxs]
+    seeds = [[1000 * w + i for i in range(3)] for w in range(4)]
+    sequential = [[plonk.create_proof(ctxs[w], keys[w][1], keys[w][3], keys[w][2], seed=sd) for sd in seeds[w]] for w in range(4)]
+    concurrent = [[None] * 3 for _ in range(4)]
+    errors = []
+
+    def work(w):
+        try:
+            for i, sd in enumerate(seeds[w]):
+                concurrent[w][i] = plonk.create_proof(ctxs[w], keys[w][1], keys[w][3], keys[w][2], seed=sd)
+        except Exception as e:  # surfaced below: an exception in a thread must fail the test
+            errors.append(e)
+
+    th = [threading.Thread(target=work, args=(w,)) for w in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    assert concurrent == sequential
+    # same seed on different contexts: same proof (contexts are interchangeable)
+    assert plonk.create_proof(ctxs[1], keys[1][1], keys[1][3], keys[1][2], seed=seeds[0][0]) == sequential[0][0]
+    assert PR.verify_proof(vk_from_device(keys[0][1], c), c.instances, sequential[0][0])
+    for (params, pk, d_adv, _), cx in zip(keys, ctxs):
+        d_adv.free(); pk.free(); params.free()
+        cx.close()
+
+
 def test_evm_proof_accepted_by_reference_solidity_verifier(ctx, pkg, plonk, oracle):
     """Config 1/3 of BASELINE.json in the form the reference can check: the SquareCircuit
     (/root/reference/src/signal.rs) proved on the MI355X with the Keccak256/EVM transcript equals the
