@@ -176,7 +176,7 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_digit_kernel(DigitArgs a) {
     Fr s;
     s.l[0] = lo.x; s.l[1] = lo.y; s.l[2] = lo.z; s.l[3] = lo.w;
     s.l[4] = hi.x; s.l[5] = hi.y; s.l[6] = hi.z; s.l[7] = hi.w;
-    Fr canon = from_mont(s);  // = to_repr() of the original
+    Fr canon = fr29_from_mont(s);  // = to_repr() of the original
     if (!SCATTER) {
       for_each_digit<C>(canon, [&](uint32_t, uint32_t b, uint32_t) { atomicAdd(&lds_cnt[b], 1u); });
     } else {

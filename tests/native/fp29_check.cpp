@@ -72,6 +72,7 @@ int main() {
     x.l[7] &= 0x0fffffffu;
     if (t == 0) x = Fr::one();
     if (t == 1) for (int i = 0; i < 8; i++) x.l[i] = FrP::p(i) - (i == 0);  // r - 1
+    if (memcmp(fr29_from_mont(x).l, from_mont(x).l, 32) != 0) { fails++; printf("fr29_from_mont\n"); if (fails > 5) return 1; }
     Fr got = fr29_inv(x), want = inv(x);
     if (memcmp(got.l, want.l, 32) != 0) { fails++; printf("fr29_inv\n"); if (fails > 5) return 1; }
   }
