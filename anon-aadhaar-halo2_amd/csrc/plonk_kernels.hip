@@ -50,7 +50,7 @@ __device__ __forceinline__ bool op_reads_col(uint32_t op) {
 template <bool R261>
 __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_kernel(ExprArgs a) {
   // the one place the two radices differ: the product (sums, differences, negation act on canonical values)
-  auto fmul = [](const Fr& x, const Fr& y) -> Fr { return R261 ? fr29_mul_rr(x, y) : mul(x, y); };
+  auto fmul = [](const Fr& x, const Fr& y) -> Fr { return R261 ? fr29_mul_rr(x, y) : fr29_mul_std(x, y); };
   extern __shared__ uint4 lds_raw[];
   Fr* stack = reinterpret_cast<Fr*>(lds_raw);  // [depth][EXPR_THREADS]
   const uint32_t tid = threadIdx.x;
@@ -160,21 +160,21 @@ __global__ __launch_bounds__(256) void batch_invert_kernel(Fr* a, Fr* scratch, s
   for (size_t i = s; i < e; i++) {
     st_fr(scratch + i, acc);
     Fr v = ld_fr(a + i);
-    if (!v.is_zero()) acc = mul(acc, v);
+    if (!v.is_zero()) acc = fr29_mul_std(acc, v);
   }
   acc = fr29_inv(acc);  // the ~380-product Fermat chain, on the in-place 29-bit product
   for (size_t i = e; i-- > s;) {
     Fr v = ld_fr(a + i);
     if (v.is_zero()) continue;
-    st_fr(a + i, mul(acc, ld_fr(scratch + i)));
-    acc = mul(acc, v);
+    st_fr(a + i, fr29_mul_std(acc, ld_fr(scratch + i)));
+    acc = fr29_mul_std(acc, v);
   }
 }
 
 // a[i] = a[i] * b[i]
 __global__ __launch_bounds__(256) void mul_elem_kernel(Fr* a, const Fr* b, size_t total) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-    st_fr(a + i, mul(ld_fr(a + i), ld_fr(b + i)));
+    st_fr(a + i, fr29_mul_std(ld_fr(a + i), ld_fr(b + i)));
 }
 
 // ------------------------------------------------------------------------------ running products
@@ -184,6 +184,11 @@ constexpr int SCAN_BLOCK = 256 * SCAN_E;
 
 __global__ __launch_bounds__(256) void scan_local_kernel(const Fr* in, Fr* out, Fr* totals, size_t n, size_t col_stride,
                                                          uint32_t nblk) {
+  // NOTE: this kernel deliberately keeps bn254.cuh's 32-bit product. With fp29.cuh's fr29_mul_std inlined here (and only
+  // here) hipcc 7.2 -O3 produces wrong running products, while the same function called out of line, and every other
+  // kernel with it inlined, is bit-exact (bisected on MI355X with the byte-equality tests; the product itself matches
+  // mul() on 3.3e6 device-side and 2e5 host-side full-range cases, tools/dev_check_mul_std.hip). The kernel is ~0.6 %
+  // of the prover's instructions, so nothing is lost by leaving it alone.
   __shared__ Fr part[256];
   const uint32_t col = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
   const Fr* src = in + (size_t)col * col_stride;
@@ -223,9 +228,9 @@ __global__ void scan_blocks_kernel(Fr* totals, const Fr* local, Fr* rel, uint32_
   for (uint32_t b = 0; b < nblk; b++) {
     Fr v = ld_fr(t + b);
     st_fr(t + b, acc);
-    acc = mul(acc, v);
+    acc = fr29_mul_std(acc, v);
   }
-  if (rel) st_fr(rel + col, mul(ld_fr(t + u / SCAN_BLOCK), ld_fr(local + (size_t)col * col_stride + u)));
+  if (rel) st_fr(rel + col, fr29_mul_std(ld_fr(t + u / SCAN_BLOCK), ld_fr(local + (size_t)col * col_stride + u)));
 }
 
 // start[0] = 1, start[c] = start[c-1] * rel[c-1]  (permutation sets chain through last_z)
@@ -234,7 +239,7 @@ __global__ void scan_chain_kernel(const Fr* rel, Fr* start, uint32_t ncols) {
   Fr acc = Fr::one();
   for (uint32_t c = 0; c < ncols; c++) {
     st_fr(start + c, acc);
-    acc = mul(acc, ld_fr(rel + c));
+    acc = fr29_mul_std(acc, ld_fr(rel + c));
   }
 }
 
@@ -245,8 +250,8 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(Fr* z, const Fr* totals
   Fr* c = z + (size_t)col * col_stride;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     Fr f = ld_fr(totals + (size_t)col * nblk + i / SCAN_BLOCK);
-    if (start) f = mul(f, ld_fr(start + col));
-    st_fr(c + i, mul(f, ld_fr(c + i)));
+    if (start) f = fr29_mul_std(f, ld_fr(start + col));
+    st_fr(c + i, fr29_mul_std(f, ld_fr(c + i)));
   }
 }
 
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(256) void lincomb_kernel(const Fr* const* polys, co
 }
 __global__ __launch_bounds__(256) void scale_kernel(Fr* a, size_t n, Fr c) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    st_fr(a + i, mul(ld_fr(a + i), c));
+    st_fr(a + i, fr29_mul_std(ld_fr(a + i), c));
 }
 
 // a[i] -= low[i] for i < m   (subtract a low-degree polynomial)
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(KD_THREADS) void kate_div_kernel(Fr* const* polys, 
   for (uint32_t d = 1; d < KD_THREADS; d <<= 1) {
     Fr v = t + d < KD_THREADS ? S[t + d] : Fr::zero();
     __syncthreads();
-    S[t] = add(S[t], mul(pw, v));
+    S[t] = add(S[t], fr29_mul_std(pw, v));
     __syncthreads();
     pw = sqr(pw);
   }
@@ -372,7 +377,7 @@ __global__ void kate_carry_kernel(const Fr* totals, Fr* carries, const Fr* roots
   Fr c = Fr::zero();
   for (uint32_t blk = nblk; blk-- > 0;) {
     st_fr(carries + (size_t)poly * nblk + blk, c);
-    c = add(ld_fr(totals + (size_t)poly * nblk + blk), mul(bl, c));
+    c = add(ld_fr(totals + (size_t)poly * nblk + blk), fr29_mul_std(bl, c));
   }
 }
 

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include "common.hpp"
+#include "fp29.cuh"
 
 using namespace bn254;
 
@@ -63,13 +64,13 @@ __global__ __launch_bounds__(256) void mul_periodic_kernel(Fr* a, size_t col_str
                                                            uint32_t mask) {
   Fr* col = a + (size_t)blockIdx.y * col_stride;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    st_fr(col + i, mul(ld_fr(col + i), ld_fr(table + (i & mask))));
+    st_fr(col + i, fr29_mul_std(ld_fr(col + i), ld_fr(table + (i & mask))));
 }
 
 // a[i] = a[i] * c  (c = R^2: canonical -> Montgomery, Fr::from_raw; c = 1: Montgomery -> canonical, to_repr)
 __global__ __launch_bounds__(256) void mul_const_kernel(Fr* a, size_t n, Fr c) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    st_fr(a + i, mul(ld_fr(a + i), c));
+    st_fr(a + i, fr29_mul_std(ld_fr(a + i), c));
 }
 
 }  // namespace

@@ -56,6 +56,7 @@ int main() {
     if (t == 0) x = Fr::zero();
     if (t == 1) c = Fr::one();
     if (t == 2) for (int i = 0; i < 8; i++) x.l[i] = FrP::p(i) - (i == 0);  // r - 1
+    if (memcmp(fr29_mul_std(x, c).l, mul(x, c).l, 32) != 0) { fails++; printf("fr29_mul_std\n"); if (fails > 5) return 1; }
     Fr c261 = fr29_const_to_r261(c);
     Fr want = mul(x, c);
     Fr got = fr29_mul_const(x, c261);
