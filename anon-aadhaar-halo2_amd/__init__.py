@@ -12,3 +12,4 @@ repository's name); import it with `__graft_entry__.load_package()` which regist
 from .ffi import AmdzkError, Context, lib, lib_path  # noqa: F401
 from . import batch  # noqa: F401
 from .halo2 import arithmetic, domain, kzg, plonk  # noqa: F401
+from . import feeder, workloads  # noqa: F401

@@ -89,6 +89,19 @@ void zk_prof_drain(amdzk_ctx* ctx) {
   ctx->pending.clear();
 }
 
+// Every device allocation this ctx owns (workspaces, twiddle tables) must live on ctx->device and its pinned
+// staging must be host memory: the check behind bench.py's per-rank assertion and tests/test_gpu_affinity.py.
+int zk_ptr_on_device(amdzk_ctx* ctx, const void* p, const char* what) {
+  if (!p) return AMDZK_OK;
+  hipPointerAttribute_t at;
+  hipError_t e = hipPointerGetAttributes(&at, p);
+  if (e != hipSuccess) ZK_FAIL(ctx, AMDZK_E_HIP, "affinity: hipPointerGetAttributes(%s) -> %s", what, hipGetErrorString(e));
+  if (at.type != hipMemoryTypeDevice || at.device != ctx->device)
+    ZK_FAIL(ctx, AMDZK_E_INVALID, "affinity: %s lives on device %d (memory type %d), ctx is on device %d", what, at.device, (int)at.type,
+            ctx->device);
+  return AMDZK_OK;
+}
+
 extern "C" {
 
 int amdzk_version(void) { return 1000; }
@@ -98,7 +111,11 @@ int amdzk_init(int device_id, amdzk_ctx** out) {
   *out = nullptr;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device_id < 0 || device_id >= count) return AMDZK_E_NO_DEVICE;
-  if (hipSetDevice(device_id) != hipSuccess) return AMDZK_E_NO_DEVICE;
+  amdzk_ctx probe;  // only `device` is read: pins this thread to device_id until return, then restores the caller's device
+  probe.device = device_id;
+  ZK_ENTER(&probe);
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess || cur != device_id) return AMDZK_E_NO_DEVICE;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return AMDZK_E_NO_DEVICE;
   // This library carries gfx950 code objects only.
@@ -118,8 +135,8 @@ int amdzk_init(int device_id, amdzk_ctx** out) {
 }
 
 void amdzk_destroy(amdzk_ctx* ctx) {
+  ZK_ENTER(ctx);
   if (!ctx) return;
-  hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   zk_prof_drain(ctx);
   for (auto& kv : ctx->twiddles) hipFree(kv.second);
@@ -129,6 +146,11 @@ void amdzk_destroy(amdzk_ctx* ctx) {
   for (auto e : ctx->evt_pool) hipEventDestroy(e);
   if (ctx->t0) hipEventDestroy(ctx->t0);
   if (ctx->t1) hipEventDestroy(ctx->t1);
+  if (ctx->copy_stream) {
+    hipStreamSynchronize(ctx->copy_stream);
+    hipStreamDestroy(ctx->copy_stream);
+  }
+  if (ctx->copy_evt) hipEventDestroy(ctx->copy_evt);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -136,6 +158,7 @@ void amdzk_destroy(amdzk_ctx* ctx) {
 const char* amdzk_last_error(const amdzk_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int amdzk_set_stream(amdzk_ctx* ctx, void* hip_stream) {
+  ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
@@ -143,18 +166,21 @@ int amdzk_set_stream(amdzk_ctx* ctx, void* hip_stream) {
 }
 
 int amdzk_sync(amdzk_ctx* ctx) {
+  ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return AMDZK_OK;
 }
 
 int amdzk_dev_alloc(amdzk_ctx* ctx, size_t bytes, void** dptr) {
+  ZK_ENTER(ctx);
   if (!ctx || !dptr) return AMDZK_E_INVALID;
   hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
   if (e != hipSuccess) ZK_FAIL(ctx, AMDZK_E_NOMEM, "dev_alloc(%zu): %s", bytes, hipGetErrorString(e));
   return AMDZK_OK;
 }
 int amdzk_dev_free(amdzk_ctx* ctx, void* dptr) {
+  ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
   if (!dptr) return AMDZK_OK;
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -162,28 +188,68 @@ int amdzk_dev_free(amdzk_ctx* ctx, void* dptr) {
   return AMDZK_OK;
 }
 int amdzk_dev_upload(amdzk_ctx* ctx, void* dptr, const void* host, size_t bytes) {
+  ZK_ENTER(ctx);
   if (!ctx || (!dptr && bytes) || (!host && bytes)) return AMDZK_E_INVALID;
   ZK_HIP(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return AMDZK_OK;
 }
 int amdzk_dev_download(amdzk_ctx* ctx, void* host, const void* dptr, size_t bytes) {
+  ZK_ENTER(ctx);
   if (!ctx || (!dptr && bytes) || (!host && bytes)) return AMDZK_E_INVALID;
   ZK_HIP(ctx, hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return AMDZK_OK;
 }
+// ---- streaming inputs: pinned host memory + uploads on a copy stream of the ctx's own
+int amdzk_host_alloc(amdzk_ctx* ctx, size_t bytes, void** hptr) {
+  ZK_ENTER(ctx);
+  if (!ctx || !hptr) return AMDZK_E_INVALID;
+  hipError_t e = hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault);
+  if (e != hipSuccess) ZK_FAIL(ctx, AMDZK_E_NOMEM, "host_alloc(%zu): %s", bytes, hipGetErrorString(e));
+  return AMDZK_OK;
+}
+int amdzk_host_free(amdzk_ctx* ctx, void* hptr) {
+  ZK_ENTER(ctx);
+  if (!ctx) return AMDZK_E_INVALID;
+  if (!hptr) return AMDZK_OK;
+  if (ctx->copy_stream) ZK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+  ZK_HIP(ctx, hipHostFree(hptr));
+  return AMDZK_OK;
+}
+int amdzk_dev_upload_async(amdzk_ctx* ctx, void* dptr, const void* host, size_t bytes) {
+  ZK_ENTER(ctx);
+  if (!ctx || (!dptr && bytes) || (!host && bytes)) return AMDZK_E_INVALID;
+  if (!ctx->copy_stream) {
+    ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->copy_evt, hipEventDisableTiming));
+  }
+  if (bytes) ZK_HIP(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+  return AMDZK_OK;
+}
+int amdzk_upload_fence(amdzk_ctx* ctx) {
+  ZK_ENTER(ctx);
+  if (!ctx) return AMDZK_E_INVALID;
+  if (!ctx->copy_stream) return AMDZK_OK;  // nothing was ever uploaded asynchronously
+  ZK_HIP(ctx, hipEventRecord(ctx->copy_evt, ctx->copy_stream));
+  ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->copy_evt, 0));
+  return AMDZK_OK;
+}
+
 int amdzk_dev_memset(amdzk_ctx* ctx, void* dptr, int byte, size_t bytes) {
+  ZK_ENTER(ctx);
   if (!ctx || (!dptr && bytes)) return AMDZK_E_INVALID;
   ZK_HIP(ctx, hipMemsetAsync(dptr, byte, bytes, ctx->stream));
   return AMDZK_OK;
 }
 
 int amdzk_srs_upload(amdzk_ctx* ctx, const uint64_t* g, const uint64_t* g_lagrange, uint32_t k, amdzk_srs** out) {
+  ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
   return zk_srs_upload(ctx, g, g_lagrange, k, out);
 }
 int amdzk_srs_setup(amdzk_ctx* ctx, uint32_t k, const uint64_t s[4], amdzk_srs** out, uint64_t* g_out, uint64_t* g_lagrange_out) {
+  ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
   if (!s || !out) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_setup: null argument");
   amdzk_domain* dom = nullptr;
@@ -202,37 +268,44 @@ static int fft_constants(amdzk_ctx* ctx, uint32_t k, uint64_t omega_inv[4], uint
   return AMDZK_OK;
 }
 int amdzk_g_to_lagrange(amdzk_ctx* ctx, const uint64_t* g, uint32_t k, uint64_t* g_lagrange_out) {
+  ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
   uint64_t wi[4], ni[4];
   ZK_TRY(fft_constants(ctx, k, wi, ni));
   return zk_g_to_lagrange(ctx, g, k, wi, ni, g_lagrange_out);
 }
 int amdzk_srs_downsize(amdzk_ctx* ctx, const amdzk_srs* srs, uint32_t new_k, amdzk_srs** out) {
+  ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
   uint64_t wi[4], ni[4];
   ZK_TRY(fft_constants(ctx, new_k, wi, ni));
   return zk_srs_downsize(ctx, srs, new_k, wi, ni, out);
 }
 int amdzk_srs_get(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, uint64_t* out) {
+  ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
   return zk_srs_get(ctx, srs, basis, out);
 }
 size_t amdzk_srs_serialized_size(uint32_t k) { return zk_srs_serialized_size(k); }
 int amdzk_srs_write(amdzk_ctx* ctx, const amdzk_srs* srs, const uint8_t g2[64], const uint8_t s_g2[64], uint8_t* out, size_t cap) {
+  ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
   return zk_srs_write(ctx, srs, g2, s_g2, out, cap);
 }
 int amdzk_srs_read(amdzk_ctx* ctx, const uint8_t* data, size_t len, amdzk_srs** out, uint8_t g2_out[64], uint8_t s_g2_out[64]) {
+  ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
   return zk_srs_read(ctx, data, len, out, g2_out, s_g2_out);
 }
 void amdzk_srs_free(amdzk_ctx* ctx, amdzk_srs* srs) {
+  ZK_ENTER(ctx);
   if (ctx) hipStreamSynchronize(ctx->stream);
   zk_srs_free(ctx, srs);
 }
 
 int amdzk_msm_g1_dev(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const void* d_scalars, size_t ncols,
                      size_t len, size_t col_stride, uint64_t* out_jacobian) {
+  ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
   if (!d_scalars || !out_jacobian) ZK_FAIL(ctx, AMDZK_E_INVALID, "msm: null pointer");
   G1X* d_res = nullptr;
@@ -242,6 +315,7 @@ int amdzk_msm_g1_dev(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const void
 
 int amdzk_msm_g1_batch(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const uint64_t* const* scalars,
                        size_t ncols, size_t len, uint64_t* out_jacobian) {
+  ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
   if (!scalars || !out_jacobian || ncols == 0) ZK_FAIL(ctx, AMDZK_E_INVALID, "msm_batch: null pointer or ncols == 0");
   Fr* d = nullptr;
@@ -256,18 +330,21 @@ int amdzk_msm_g1_batch(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const ui
 
 int amdzk_msm_g1(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const uint64_t* scalars, size_t len,
                  uint64_t out_jacobian[12]) {
+  ZK_ENTER(ctx);
   const uint64_t* cols[1] = {scalars};
   return amdzk_msm_g1_batch(ctx, srs, basis, cols, 1, len, out_jacobian);
 }
 
 int amdzk_ntt_fr_dev(amdzk_ctx* ctx, void* d_a, uint32_t log_n, const uint64_t omega[4], uint32_t flags,
                      size_t ncols, size_t col_stride) {
+  ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
   if (!d_a || !omega) ZK_FAIL(ctx, AMDZK_E_INVALID, "ntt: null pointer");
   return zk_ntt_dev(ctx, (Fr*)d_a, log_n, omega, flags, ncols, col_stride);
 }
 
 int amdzk_ntt_fr(amdzk_ctx* ctx, uint64_t* a, uint32_t log_n, const uint64_t omega[4], uint32_t flags) {
+  ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
   if (!a || !omega) ZK_FAIL(ctx, AMDZK_E_INVALID, "ntt: null pointer");
   if (log_n > 27) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "ntt: log_n %u > 27", log_n);
@@ -281,12 +358,31 @@ int amdzk_ntt_fr(amdzk_ctx* ctx, uint64_t* a, uint32_t log_n, const uint64_t ome
   return AMDZK_OK;
 }
 
+int amdzk_ctx_check_affinity(amdzk_ctx* ctx) {
+  ZK_ENTER(ctx);
+  if (!ctx) return AMDZK_E_INVALID;
+  int dev = -1;
+  ZK_HIP(ctx, hipStreamGetDevice(ctx->stream, &dev));
+  if (dev != ctx->device) ZK_FAIL(ctx, AMDZK_E_INVALID, "affinity: stream is on device %d, ctx on %d", dev, ctx->device);
+  for (int i = 0; i < 8; i++) ZK_TRY(zk_ptr_on_device(ctx, ctx->ws[i].p, "workspace"));
+  for (auto& kv : ctx->twiddles) ZK_TRY(zk_ptr_on_device(ctx, kv.second, "twiddle table"));
+  return AMDZK_OK;
+}
+int amdzk_ptr_check_affinity(amdzk_ctx* ctx, const void* dptr) {
+  ZK_ENTER(ctx);
+  if (!ctx) return AMDZK_E_INVALID;
+  return zk_ptr_on_device(ctx, dptr, "pointer");
+}
+int amdzk_ctx_device(const amdzk_ctx* ctx) { return ctx ? ctx->device : -1; }
+
 int amdzk_timer_start(amdzk_ctx* ctx) {
+  ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
   ZK_HIP(ctx, hipEventRecord(ctx->t0, ctx->stream));
   return AMDZK_OK;
 }
 int amdzk_timer_stop(amdzk_ctx* ctx, float* ms) {
+  ZK_ENTER(ctx);
   if (!ctx || !ms) return AMDZK_E_INVALID;
   ZK_HIP(ctx, hipEventRecord(ctx->t1, ctx->stream));
   ZK_HIP(ctx, hipEventSynchronize(ctx->t1));
@@ -294,18 +390,21 @@ int amdzk_timer_stop(amdzk_ctx* ctx, float* ms) {
   return AMDZK_OK;
 }
 int amdzk_prof_enable(amdzk_ctx* ctx, int on) {
+  ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
   zk_prof_drain(ctx);
   ctx->prof = on != 0;
   return AMDZK_OK;
 }
 int amdzk_prof_reset(amdzk_ctx* ctx) {
+  ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
   zk_prof_drain(ctx);
   ctx->prof_map.clear();
   return AMDZK_OK;
 }
 int amdzk_prof_get(amdzk_ctx* ctx, const char* kernel_name, uint64_t* launches, double* total_ms) {
+  ZK_ENTER(ctx);
   if (!ctx || !kernel_name) return AMDZK_E_INVALID;
   zk_prof_drain(ctx);
   auto it = ctx->prof_map.find(kernel_name);
@@ -314,6 +413,7 @@ int amdzk_prof_get(amdzk_ctx* ctx, const char* kernel_name, uint64_t* launches, 
   return AMDZK_OK;
 }
 size_t amdzk_prof_dump(amdzk_ctx* ctx, char* buf, size_t cap) {
+  ZK_ENTER(ctx);
   if (!ctx) return 0;
   zk_prof_drain(ctx);
   std::string s;

@@ -37,6 +37,9 @@ struct amdzk_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
+  // second stream for amdzk_dev_upload_async (created on first use) and the event its fence waits on
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t copy_evt = nullptr;
   std::string err;
   int num_cu = 256;
 
@@ -81,6 +84,27 @@ struct amdzk_ctx {
     }                                                                                      \
   } while (0)
 
+// HIP's current device is a per-host-thread setting, while an amdzk_ctx belongs to ONE device: every extern "C"
+// entry point that can touch the device pins the calling thread to ctx->device for the duration of the call and
+// restores the caller's device on the way out. Without this a ctx created on one thread and used from another
+// (bench.py's proof workers, a Rust rayon thread) would allocate its workspaces on device 0 while its stream
+// lives on ctx->device.
+struct ZkDeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit ZkDeviceGuard(const amdzk_ctx* ctx) {
+    if (!ctx) return;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != ctx->device) switched = hipSetDevice(ctx->device) == hipSuccess && prev >= 0;
+  }
+  ~ZkDeviceGuard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  ZkDeviceGuard(const ZkDeviceGuard&) = delete;
+  ZkDeviceGuard& operator=(const ZkDeviceGuard&) = delete;
+};
+#define ZK_ENTER(ctx) ZkDeviceGuard _zk_device_guard(ctx)
+
 #define ZK_TRY(expr)            \
   do {                          \
     int _r = (expr);            \
@@ -89,6 +113,7 @@ struct amdzk_ctx {
 
 int zk_ws_reserve(amdzk_ctx* ctx, int slot, size_t bytes, void** out);
 int zk_pinned_reserve(amdzk_ctx* ctx, size_t bytes, void** out);
+int zk_ptr_on_device(amdzk_ctx* ctx, const void* p, const char* what);
 hipEvent_t zk_evt_get(amdzk_ctx* ctx);
 void zk_prof_drain(amdzk_ctx* ctx);
 

@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void mul_const_kernel(Fr* a, size_t n, Fr c) {
 extern "C" {
 
 int amdzk_fr_from_raw_dev(amdzk_ctx* ctx, void* d_a, size_t n) {
+  ZK_ENTER(ctx);
   if (!ctx || (!d_a && n)) return AMDZK_E_INVALID;
   unsigned gx = (unsigned)((n + 255) / 256);
   if (gx > 4096) gx = 4096;
@@ -85,6 +86,7 @@ int amdzk_fr_from_raw_dev(amdzk_ctx* ctx, void* d_a, size_t n) {
   return AMDZK_OK;
 }
 int amdzk_fr_to_repr_dev(amdzk_ctx* ctx, void* d_a, size_t n) {
+  ZK_ENTER(ctx);
   if (!ctx || (!d_a && n)) return AMDZK_E_INVALID;
   unsigned gx = (unsigned)((n + 255) / 256);
   if (gx > 4096) gx = 4096;
@@ -95,6 +97,7 @@ int amdzk_fr_to_repr_dev(amdzk_ctx* ctx, void* d_a, size_t n) {
 }
 
 int amdzk_domain_new(amdzk_ctx* ctx, uint32_t j, uint32_t k, amdzk_domain** out) {
+  ZK_ENTER(ctx);
   if (!ctx || !out) return AMDZK_E_INVALID;
   if (j < 2) ZK_FAIL(ctx, AMDZK_E_INVALID, "domain_new: degree j = %u < 2", j);
   amdzk_domain* d = new amdzk_domain();
@@ -143,6 +146,7 @@ int amdzk_domain_new(amdzk_ctx* ctx, uint32_t j, uint32_t k, amdzk_domain** out)
 }
 
 void amdzk_domain_free(amdzk_ctx* ctx, amdzk_domain* d) {
+  ZK_ENTER(ctx);
   if (!d) return;
   if (ctx) hipStreamSynchronize(ctx->stream);
   if (d->d_t_evaluations) hipFree(d->d_t_evaluations);
@@ -163,18 +167,21 @@ uint32_t amdzk_domain_k(const amdzk_domain* d) { return d ? d->k : 0; }
 uint32_t amdzk_domain_extended_k(const amdzk_domain* d) { return d ? d->extended_k : 0; }
 
 int amdzk_lagrange_to_coeff_dev(amdzk_ctx* ctx, const amdzk_domain* d, void* d_cols, size_t ncols, size_t col_stride) {
+  ZK_ENTER(ctx);
   if (!ctx || !d || !d_cols) return AMDZK_E_INVALID;
   Fr oc[3] = {d->ifft_divisor, d->ifft_divisor, d->ifft_divisor};
   return zk_ntt_ex(ctx, (Fr*)d_cols, col_stride, (Fr*)d_cols, col_stride, d->k, (const uint64_t*)d->omega_inv.l, ncols, 0, nullptr, oc, nullptr);
 }
 
 int amdzk_coeff_to_lagrange_dev(amdzk_ctx* ctx, const amdzk_domain* d, void* d_cols, size_t ncols, size_t col_stride) {
+  ZK_ENTER(ctx);
   if (!ctx || !d || !d_cols) return AMDZK_E_INVALID;
   return zk_ntt_ex(ctx, (Fr*)d_cols, col_stride, (Fr*)d_cols, col_stride, d->k, (const uint64_t*)d->omega.l, ncols, 0, nullptr, nullptr, nullptr);
 }
 
 int amdzk_coeff_to_extended_dev(amdzk_ctx* ctx, const amdzk_domain* d, const void* d_coeff, size_t in_stride,
                                 void* d_ext, size_t out_stride, size_t ncols) {
+  ZK_ENTER(ctx);
   if (!ctx || !d || !d_coeff || !d_ext) return AMDZK_E_INVALID;
   Fr ic[2] = {d->g_coset, d->g_coset_inv};
   return zk_ntt_ex(ctx, (const Fr*)d_coeff, in_stride, (Fr*)d_ext, out_stride, d->extended_k,
@@ -207,6 +214,7 @@ int zk_extended_to_coeff_from_r261(amdzk_ctx* ctx, const amdzk_domain* d, Fr* d_
 }
 
 int amdzk_extended_to_coeff_dev(amdzk_ctx* ctx, const amdzk_domain* d, void* d_ext, size_t ncols, size_t col_stride) {
+  ZK_ENTER(ctx);
   if (!ctx || !d || !d_ext) return AMDZK_E_INVALID;
   // ifft divisor and the inverse coset powers [1, zeta^-1 = zeta^2, zeta^-2 = zeta] in one multiplier
   Fr oc[3] = {d->extended_ifft_divisor, mul(d->extended_ifft_divisor, d->g_coset_inv), mul(d->extended_ifft_divisor, d->g_coset)};
@@ -215,6 +223,7 @@ int amdzk_extended_to_coeff_dev(amdzk_ctx* ctx, const amdzk_domain* d, void* d_e
 }
 
 int amdzk_divide_by_vanishing_dev(amdzk_ctx* ctx, const amdzk_domain* d, void* d_ext, size_t ncols, size_t col_stride) {
+  ZK_ENTER(ctx);
   if (!ctx || !d || !d_ext) return AMDZK_E_INVALID;
   const size_t n = (size_t)1 << d->extended_k;
   unsigned gx = (unsigned)((n + 255) / 256);

@@ -520,6 +520,7 @@ void trace_pt(const char* label, const G1Affine& p) {
 extern "C" {
 
 void amdzk_pk_free(amdzk_ctx* ctx, amdzk_pk* pk) {
+  ZK_ENTER(ctx);
   if (!pk) return;
   if (ctx) hipStreamSynchronize(ctx->stream);
   for (void* p : pk->allocs) hipFree(p);
@@ -528,8 +529,17 @@ void amdzk_pk_free(amdzk_ctx* ctx, amdzk_pk* pk) {
   delete pk;
 }
 
+// Every device allocation of the key (columns, cosets, per-proof workspace) must live on ctx's device.
+int amdzk_pk_check_affinity(amdzk_ctx* ctx, const amdzk_pk* pk) {
+  ZK_ENTER(ctx);
+  if (!ctx || !pk) return AMDZK_E_INVALID;
+  for (void* p : pk->allocs) ZK_TRY(zk_ptr_on_device(ctx, p, "proving-key buffer"));
+  return AMDZK_OK;
+}
+
 int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, const uint64_t* fixed_values, const uint32_t* perm_mapping,
                  const uint64_t transcript_repr[4], amdzk_pk** out) {
+  ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
   if (!srs || !c || !out || !transcript_repr) ZK_FAIL(ctx, AMDZK_E_INVALID, "keygen: null argument");
   if (c->cs_degree < 3) ZK_FAIL(ctx, AMDZK_E_INVALID, "keygen: cs_degree %u < 3", c->cs_degree);
@@ -1070,6 +1080,7 @@ size_t amdzk_proof_size(const amdzk_pk* pk, int format) {
 int amdzk_create_proof_scalars(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances, const size_t* instance_lens,
                                const void* d_advice, size_t advice_stride, const uint64_t* scalars, size_t scalar_count, int transcript_kind,
                                uint8_t* proof_out, size_t proof_cap, size_t* proof_len) {
+  ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
   if (!pk || !scalars) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof_scalars: null argument");
   if (scalar_count < amdzk_proof_random_count(pk))
@@ -1082,6 +1093,7 @@ int amdzk_create_proof_scalars(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* con
 
 int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances, const size_t* instance_lens, const void* d_advice,
                        size_t advice_stride, uint64_t rng_seed, uint8_t* proof_out, size_t proof_cap, size_t* proof_len) {
+  ZK_ENTER(ctx);
   return amdzk_create_proof_ex(ctx, pk, instances, instance_lens, d_advice, advice_stride, rng_seed, AMDZK_TRANSCRIPT_BLAKE2B, proof_out,
                                proof_cap, proof_len);
 }
@@ -1089,6 +1101,7 @@ int amdzk_create_proof(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* inst
 int amdzk_create_proof_ex(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances, const size_t* instance_lens, const void* d_advice,
                           size_t advice_stride, uint64_t rng_seed, int transcript_kind, uint8_t* proof_out, size_t proof_cap,
                           size_t* proof_len) {
+  ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
   ChaCha20Rng chacha(rng_seed);
   RandomSource rs;
@@ -1099,6 +1112,7 @@ int amdzk_create_proof_ex(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* i
 static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances, const size_t* instance_lens, const void* d_advice,
                              size_t advice_stride, RandomSource& rng, int transcript_kind, uint8_t* proof_out, size_t proof_cap,
                              size_t* proof_len) {
+  ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
   if (!pk || !proof_len || (pk->A && !d_advice)) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: null argument");
   const size_t n = pk->n, ext = pk->ext;

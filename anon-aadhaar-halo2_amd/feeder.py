@@ -1,0 +1,75 @@
+"""Streaming witnesses: the device half of what a caller sees after `Circuit::synthesize`
+(/root/reference/src/lib.rs:328-397) — SURVEY.md §8(f) rank 2.
+
+The reference synthesizes one witness per proof on the host (Rust chips; not built here). What the backend owes
+that caller is that handing over a fresh host witness per proof costs as little as possible: each in-flight
+proving context owns two device buffers; while proof i runs out of one, the witness of proof i+1 is copied from
+pinned host memory into the other on the context's copy stream (amdzk_dev_upload_async), and the create_proof
+that reads it is ordered behind the copy on the device (amdzk_upload_fence) — no host wait, no pageable staging.
+"""
+import numpy as np
+
+
+class PinnedWitness:
+    """One witness (num_advice x n Fr, Montgomery form — what halo2's Assigned::evaluate leaves on the host) in
+    hipHostMalloc'd memory."""
+
+    def __init__(self, ctx, num_advice, n):
+        self.shape = (num_advice, n, 4)
+        self.nbytes = num_advice * n * 32
+        self.buf = ctx.alloc_pinned(self.nbytes)
+        self.array = self.buf.array(self.shape, np.uint64)
+
+    @property
+    def ptr(self):
+        return self.buf.ptr.value
+
+    def free(self):
+        self.array = None
+        self.buf.free()
+
+
+class WitnessStream:
+    """Double-buffered device staging for ONE proving context (one proof at a time per context)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, nbytes
+        self.bufs = [ctx.alloc(nbytes), ctx.alloc(nbytes)]
+        self.cur = 0
+        self.pending = False
+
+    def prefetch(self, pinned):
+        """Start copying `pinned` (PinnedWitness) into the idle buffer. The previous reader of that buffer — the
+        proof before the current one — has returned, so the buffer is free."""
+        assert not self.pending, "one prefetch per acquire"
+        assert pinned.nbytes <= self.nbytes
+        self.ctx.upload_async(self.bufs[self.cur ^ 1], pinned.ptr, pinned.nbytes)
+        self.pending = True
+
+    def acquire(self):
+        """The buffer holding the most recently prefetched witness; everything submitted to the ctx from now on
+        runs after its copy."""
+        assert self.pending, "acquire without prefetch"
+        self.ctx.upload_fence()
+        self.cur ^= 1
+        self.pending = False
+        return self.bufs[self.cur]
+
+    def free(self):
+        for b in self.bufs:
+            b.free()
+
+
+def prove_stream(plonk, ctx, pk, stream, items, transcript=0):
+    """create_proof for each (pinned_witness, instances, seed) of `items` on one context, with the next witness's
+    upload overlapped with the current proof. Returns the proofs in order."""
+    out = []
+    if not items:
+        return out
+    stream.prefetch(items[0][0])
+    for j, (_, inst, seed) in enumerate(items):
+        buf = stream.acquire()
+        if j + 1 < len(items):
+            stream.prefetch(items[j + 1][0])
+        out.append(plonk.create_proof(ctx, pk, inst, buf, seed=seed, transcript=transcript))
+    return out

@@ -35,11 +35,19 @@ def lib():
         "amdzk_last_error": (C.c_char_p, [vp]),
         "amdzk_set_stream": (i32, [vp, vp]),
         "amdzk_sync": (i32, [vp]),
+        "amdzk_ctx_device": (i32, [vp]),
+        "amdzk_ctx_check_affinity": (i32, [vp]),
+        "amdzk_ptr_check_affinity": (i32, [vp, vp]),
+        "amdzk_pk_check_affinity": (i32, [vp, vp]),
         "amdzk_dev_alloc": (i32, [vp, sz, C.POINTER(vp)]),
         "amdzk_dev_free": (i32, [vp, vp]),
         "amdzk_dev_upload": (i32, [vp, vp, vp, sz]),
         "amdzk_dev_download": (i32, [vp, vp, vp, sz]),
         "amdzk_dev_memset": (i32, [vp, vp, i32, sz]),
+        "amdzk_host_alloc": (i32, [vp, sz, C.POINTER(vp)]),
+        "amdzk_host_free": (i32, [vp, vp]),
+        "amdzk_dev_upload_async": (i32, [vp, vp, vp, sz]),
+        "amdzk_upload_fence": (i32, [vp]),
         "amdzk_srs_upload": (i32, [vp, vp, vp, u32, C.POINTER(vp)]),
         "amdzk_srs_setup": (i32, [vp, u32, vp, C.POINTER(vp), vp, vp]),
         "amdzk_srs_serialized_size": (sz, [u32]),
@@ -128,6 +136,27 @@ class DeviceBuffer:
             self.ptr = None
 
 
+class PinnedBuffer:
+    """hipHostMalloc'd staging memory (amdzk_host_alloc), viewed as a numpy array."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, nbytes
+        p = C.c_void_p()
+        ctx._chk(ctx.L.amdzk_host_alloc(ctx.h, nbytes, C.byref(p)))
+        self.ptr = p
+
+    def array(self, shape, dtype=np.uint64):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        assert n <= self.nbytes
+        buf = (C.c_uint8 * n).from_address(self.ptr.value)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.ctx.L.amdzk_host_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+
 class Context:
     """amdzk_ctx wrapper. Raises AmdzkError (never falls back to the CPU)."""
 
@@ -157,11 +186,32 @@ class Context:
     def sync(self):
         self._chk(self.L.amdzk_sync(self.h))
 
+    def device(self):
+        return self.L.amdzk_ctx_device(self.h)
+
+    def check_affinity(self, pk=None, ptr=None):
+        """Raise unless the ctx's stream / workspaces (and `pk`'s buffers, and `ptr`) live on the ctx's device."""
+        self._chk(self.L.amdzk_ctx_check_affinity(self.h))
+        if pk is not None:
+            self._chk(self.L.amdzk_pk_check_affinity(self.h, pk))
+        if ptr is not None:
+            self._chk(self.L.amdzk_ptr_check_affinity(self.h, C.c_void_p(ptr)))
+
     def set_stream(self, stream_ptr):
         self._chk(self.L.amdzk_set_stream(self.h, C.c_void_p(stream_ptr)))
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
+
+    def alloc_pinned(self, nbytes):
+        return PinnedBuffer(self, nbytes)
+
+    def upload_async(self, dbuf, host_ptr, nbytes):
+        """Start a host->device copy on the ctx's copy stream (host_ptr: address of pinned memory)."""
+        self._chk(self.L.amdzk_dev_upload_async(self.h, dbuf.ptr, C.c_void_p(host_ptr), nbytes))
+
+    def upload_fence(self):
+        self._chk(self.L.amdzk_upload_fence(self.h))
 
     # ---- timing hooks
     def timer_start(self):

@@ -1,317 +1,552 @@
 #!/usr/bin/env python3
 """bench.py — create_proof throughput on MI355X (contract: see the task brief).
 
-One "step" = ONE full `create_proof` (KZG/SHPLONK/Blake2b, halo2_proofs v2023_01_20 semantics) of the
-composite Aadhaar verifier circuit's budget (default --shape full: /root/reference/src/aadhaar_verifier_circuit.rs:49-56
-= the RSA-SHA256 shape of /root/reference/src/lib.rs:263-274,295-326 at k = 15 — 80 vertical-gate advice
-+ 16 range-lookup advice + 16 SHA spread advice columns, 24 lookups, 115 permutation columns -> 58 grand
-products, degree 4 so extended_k = 17 — plus the IdentityCircuit / TimestampCircuit / SquareCircuit
-columns and gates: 141 advice, 118 permutation columns; --shape k15 / k18 = the RSA-SHA256 sub-circuit
-alone), on a synthetic satisfying
-witness that is already resident in HBM when the timed region starts. Each step
-draws fresh blinding (seed = step index) and recomputes everything: 248 MSMs, 244 iNTTs, 244 coset
-NTTs, the h(X) evaluation over 2^17 rows, 58+24 grand products, ~900 evaluations, SHPLONK. Witness
-synthesis (the reference's Rust chips) and keygen are outside the step, as in upstream's own split.
-The SRS is a real one (g[i] = s^i G, g_lagrange[i] = L_i(s) G, built on the device), so the proofs are
-valid; tests/test_gpu_prover.py verifies this same circuit's proof with the oracle's verifier.
+One "step" = ONE full `create_proof` (KZG/SHPLONK/Blake2b, halo2_proofs v2023_01_20 semantics) of the composite
+Aadhaar verifier circuit's budget (default --shape full: /root/reference/src/aadhaar_verifier_circuit.rs:49-56 = the
+RSA-SHA256 shape of /root/reference/src/lib.rs:263-274,295-326 at k = 15 — 80 vertical-gate advice + 16 range-lookup
+advice + 16 SHA spread advice columns, 24 lookups, 115 permutation columns -> 58 grand products, degree 4 so
+extended_k = 17 — plus the IdentityCircuit / TimestampCircuit / SquareCircuit columns and gates: 141 advice, 118
+permutation columns; --shape k15 / k18 = the RSA-SHA256 sub-circuit alone; the shapes live in
+anon-aadhaar-halo2_amd/workloads.py), on synthetic satisfying witnesses that are already resident in HBM when the
+timed region starts. Each step draws fresh blinding (seed = step index), takes the next of the
+resident witnesses and recomputes everything: 248 MSMs, 244 iNTTs, 244 coset NTTs, the h(X) evaluation over 2^17
+rows, 58+24 grand products, ~900 evaluations, SHPLONK. Witness synthesis (the reference's Rust chips) and keygen are
+outside the step, as in upstream's own split. The SRS is a real one (g[i] = s^i G, g_lagrange[i] = L_i(s) G, built on
+the device), so the proofs are valid; tests/test_gpu_prover.py verifies this circuit's proof with the oracle's verifier.
 
-N > 1: independent proofs shard one-per-GPU (weak scaling); the only collective is the gather of
-the finished proof bytes (fixed length), an RCCL all_gather.
+Launching: `python bench.py --gpus N` starts N ranks itself (one child process per GPU, before anything in the parent
+touches HIP); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is one of the ranks
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment). N > 1: independent proofs, one shard per GPU (weak
+scaling); the only collective is the gather of the finished proof bytes (fixed length), an RCCL all_gather.
+`--batch B` is BASELINE config 4: B independent witnesses (seeds 0..B-1), proof i on rank i mod N, gathered on all ranks.
+
+After the timed region every rank repeats the steps with one host->device witness upload per proof (pinned memory,
+copy stream, double-buffered per in-flight context: anon-aadhaar-halo2_amd/feeder.py) and the line reports that
+PCIe-inclusive rate next to the resident one (config.pcie_inclusive_proofs_per_s); `value` is always the resident rate.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0
 R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
-
-SHAPES = {
-    # the reference's own configuration (src/lib.rs:263-274, k = 15 at src/lib.rs:444)
-    "k15": dict(k=15, num_advice=80, num_lookup_advice=16, lookup_bits=12, num_spread=8, spread_bits=8),
-    # BASELINE.json configs[1] "k~18": same area, 8x fewer gate columns
-    "k18": dict(k=18, num_advice=10, num_lookup_advice=2, lookup_bits=12, num_spread=1, spread_bits=8),
-    # BASELINE.json configs[2]: the composite AadhaarQRVerifierCircuit budget (src/aadhaar_verifier_circuit.rs:49-56):
-    # k15 + IdentityCircuit + TimestampCircuit + SquareCircuit columns and gates
-    "full": dict(k=15, num_advice=80, num_lookup_advice=16, lookup_bits=12, num_spread=8, spread_bits=8, composite=True),
-}
+SHAPE_NAMES = ("full", "k15", "k18")
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20,
+                    help="timed proofs per GPU; the default gives five full rounds of 4 in flight, so pipeline fill/drain is a small share")
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--shape", default="full", choices=SHAPE_NAMES,
+                    help="full = composite Aadhaar verifier budget at k = 15 (the metric's configuration); k15 / k18 = RSA-SHA256 sub-circuit shapes")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="BASELINE config 4: this many independent witnesses (seeds 0..B-1) over all ranks, proof i on rank i mod N; "
+                         "overrides --steps with B / N")
+    ap.add_argument("--witnesses", type=int, default=0, help="distinct resident witnesses per GPU the steps cycle through (0 = auto: 4, or all of them with --batch)")
+    ap.add_argument("--concurrency", type=int, default=int(os.environ.get("AMDZK_BENCH_CONCURRENCY", "0")),
+                    help="proofs in flight per GPU (each on its own amdzk context / HIP stream / proving-key workspace); "
+                         "0 = auto: a divisor of --steps among 4, 5, 3, 6 (so the timed steps form whole rounds), else 4")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stream-pass", action="store_true", help="skip the PCIe-inclusive pass (one witness upload per proof)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------ launcher
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv, worker=None, env_extra=None, timeout=None):
+    """Start n ranks of this script (one child per GPU) and wait for them. Runs BEFORE the parent has imported torch
+    or touched HIP; the children are fresh interpreters (never an exec of a process that initialised the GPU). Rank 0's
+    stdout is ours (the one JSON line); the other ranks' stdout goes to stderr. Returns the exit code."""
+    port = free_port()
+    cmd = list(worker) if worker else [sys.executable, os.path.abspath(__file__)]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if env_extra:
+            env.update(env_extra)
+        procs.append(subprocess.Popen(cmd + list(argv), env=env, stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    t_end = None if timeout is None else time.time() + timeout
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:  # one rank failed: the others would wait in a collective forever
+                    q.terminate()
+        if live:
+            if t_end is not None and time.time() > t_end:
+                rc = rc or 124
+                for q in live:
+                    q.kill()
+            time.sleep(0.05)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------ provers
 class DevView:
     def __init__(self, ptr):
         import ctypes
         self.ptr = ctypes.c_void_p(ptr)
 
 
-def canon_limbs(cols):
-    """list of columns of Python ints -> (ncols, n, 4) uint64 canonical limbs."""
-    out = np.zeros((len(cols), len(cols[0]), 4), dtype=np.uint64)
-    mask = (1 << 64) - 1
-    for c, col in enumerate(cols):
-        small = all(v < (1 << 63) for v in col)
-        if small:
-            out[c, :, 0] = np.array(col, dtype=np.uint64)
-            continue
-        for i, v in enumerate(col):
-            if v:
-                out[c, i, 0] = v & mask
-                if v >> 64:
-                    out[c, i, 1] = (v >> 64) & mask
-                    out[c, i, 2] = (v >> 128) & mask
-                    out[c, i, 3] = v >> 192
-    return out
+def mont_limbs(v):
+    import numpy as np
+    return np.array([((v << 256) % R >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20,
-                    help="timed proofs per GPU; the default gives five full rounds of 4 in flight, so pipeline fill/drain is a small share")
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--shape", default="full", choices=sorted(SHAPES),
-                    help="full = composite Aadhaar verifier budget at k = 15 (the metric's configuration); k15 / k18 = RSA-SHA256 sub-circuit shapes")
-    ap.add_argument("--concurrency", type=int, default=int(os.environ.get("AMDZK_BENCH_CONCURRENCY", "0")),
-                    help="proofs in flight per GPU (each on its own amdzk context / HIP stream / proving-key workspace); "
-                         "0 = auto: a divisor of --steps among 4, 5, 3, 6 (so the timed steps form whole rounds), else 4")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+class GpuProver:
+    """P proving contexts on one GPU over one circuit layout and `nw` resident witnesses."""
 
-    import torch
-    import torch.distributed as dist
+    def __init__(self, args, rank, local_rank, P, witness_seeds, want_host_srs):
+        import numpy as np
+        import torch
+        import __graft_entry__ as ge
 
-    import __graft_entry__ as ge
-    import circuits
+        self.np, self.torch = np, torch
+        pkg = self.pkg = ge.load_package()
+        self.plonk = pkg.plonk
+        wl = pkg.workloads
+        self.P = P
+        self.ctxs = [pkg.Context(local_rank) for _ in range(P)]
+        ctx = self.ctx = self.ctxs[0]
+        t0 = time.perf_counter()
+        c = self.circuit = wl.make(args.shape, seed=witness_seeds[0])
+        self.desc = c.desc
+        self.K = c.k
+        self.n = 1 << c.k
+        self.s_int = 0x0123456789ABCDEF0123456789ABCDEF % R
+        self.tr_int = 0xA11CE
+        self.params = pkg.kzg.ParamsKZG.setup(ctx, self.K, mont_limbs(self.s_int), want_host_copy=want_host_srs)
+        fixed_host = self.to_mont_dev(c.fixed).cpu().numpy().view(np.uint64)
+        tr = mont_limbs(self.tr_int)
+        self.pks = [self.plonk.ProvingKey(cx, self.params, self.desc, fixed_host, c.assembly.mapping, tr) for cx in self.ctxs]
+        # resident witnesses (Montgomery form, device) + the same in pinned host memory for the PCIe-inclusive pass
+        self.witness_ints = []
+        self.adv, self.inst = [], []
+        for j, ws in enumerate(witness_seeds):
+            advice, instances = (c.advice, c.instances) if j == 0 else c.witness(ws)
+            if j == 0:
+                self.witness_ints.append((advice, instances))
+            self.adv.append(self.to_mont_dev(advice))  # (A, n, 4) int64 view of u64 limbs
+            self.inst.append([self.to_mont_dev([col]).cpu().numpy().view(np.uint64)[0] if col else np.zeros((0, 4), np.uint64)
+                              for col in instances])
+        self.d_adv = [DevView(t.data_ptr()) for t in self.adv]
+        self.pinned, self.streams = None, None
+        self.setup_s = time.perf_counter() - t0
 
-    pkg = ge.load_package()
-    plonk = pkg.plonk
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a gfx950 GPU (there is no CPU fallback in the product path)")
-    # AMDZK_BENCH_FORCE_DEVICE / AMDZK_BENCH_BACKEND exist only to rehearse the N>1 code path on a
-    # one-GPU box (all ranks on device 0, gloo instead of RCCL); the driver never sets them.
-    if os.environ.get("AMDZK_BENCH_FORCE_DEVICE") is not None:
-        local_rank = int(os.environ["AMDZK_BENCH_FORCE_DEVICE"])
-    backend = os.environ.get("AMDZK_BENCH_BACKEND", "nccl")
-    coll_dev = "cuda" if backend == "nccl" else "cpu"
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-    P = args.concurrency
-    if P <= 0:
-        divs = [d for d in (4, 5, 3, 6) if args.steps % d == 0]  # 4 in flight measured best (profiles/r01e)
-        P = divs[0] if divs else min(4, max(1, args.steps))
-    ctxs = [pkg.Context(local_rank) for _ in range(P)]
-    ctx = ctxs[0]
-
-    shape = dict(SHAPES[args.shape])
-    make_circuit = circuits.full_aadhaar_shape if shape.pop("composite", False) else circuits.rsa_sha256_shape
-    K = shape["k"]
-    n = 1 << K
-    t_setup = time.perf_counter()
-    c = make_circuit(plonk, seed=7 + rank, **shape)
-    desc = c.desc
-
-    def to_mont_dev(cols):
-        lim = canon_limbs(cols)
-        t = torch.from_numpy(lim.view(np.int64)).cuda()
-        ctx._chk(ctx.L.amdzk_fr_from_raw_dev(ctx.h, t.data_ptr(), t.numel() // 4))
-        ctx.sync()
+    def to_mont_dev(self, cols):
+        lim = self.pkg.workloads.canon_limbs(cols)
+        t = self.torch.from_numpy(lim.view(self.np.int64)).cuda()
+        self.ctx._chk(self.ctx.L.amdzk_fr_from_raw_dev(self.ctx.h, t.data_ptr(), t.numel() // 4))
+        self.ctx.sync()
         return t
 
-    mont = lambda v: np.array([((v << 256) % R >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
-    s_int = 0x0123456789ABCDEF0123456789ABCDEF % R
-    want_cpu = rank == 0 and not args.no_cpu_baseline
-    params = pkg.kzg.ParamsKZG.setup(ctx, K, mont(s_int), want_host_copy=want_cpu)
-    fixed_host = to_mont_dev(c.fixed).cpu().numpy().view(np.uint64)
-    tr_int = 0xA11CE
-    tr = mont(tr_int)
-    pks = [plonk.ProvingKey(cx, params, desc, fixed_host, c.assembly.mapping, tr) for cx in ctxs]
-    pk = pks[0]
-    adv = to_mont_dev(c.advice)  # resident witness, (A, n, 4)
-    inst = [to_mont_dev([col]).cpu().numpy().view(np.uint64)[0] if col else np.zeros((0, 4), np.uint64) for col in c.instances]
-    d_adv = DevView(adv.data_ptr())
-    t_setup = time.perf_counter() - t_setup
+    def prove(self, w, wi, seed):
+        return self.plonk.create_proof(self.ctxs[w], self.pks[w], self.inst[wi], self.d_adv[wi], seed=seed)
 
-    import threading
+    def sync(self):
+        for cx in self.ctxs:
+            cx.sync()
+        self.torch.cuda.synchronize()
 
-    proofs = []
+    def check_affinity(self):
+        """Every context's stream / workspaces and every key's buffers must live on this rank's GPU."""
+        for cx, pk in zip(self.ctxs, self.pks):
+            cx.check_affinity(pk=pk.h)
+        for t in self.adv:
+            self.ctx.check_affinity(ptr=t.data_ptr())
 
-    def step(i, w=0):
-        proofs.append(plonk.create_proof(ctxs[w], pks[w], inst, d_adv, seed=1000 * rank + i))
+    # ---- PCIe-inclusive pass
+    def stream_setup(self):
+        fd = self.pkg.feeder
+        A = self.desc["num_advice"]
+        self.pinned = []
+        for t in self.adv:
+            pw = fd.PinnedWitness(self.ctx, A, self.n)
+            pw.array[...] = t.cpu().numpy().view(self.np.uint64)
+            self.pinned.append(pw)
+        self.streams = [fd.WitnessStream(cx, A * self.n * 32) for cx in self.ctxs]
 
-    def run_steps(first, count):
-        """`count` proofs, up to P in flight: worker w owns context w; ctypes drops the GIL inside the
-        C call, so the host drivers of different proofs overlap and their kernels interleave on the GPU."""
-        nxt = iter(range(first, first + count))
-        lock = threading.Lock()
-        results = {}
+    def prove_stream(self, w, jobs):
+        """jobs: [(witness index, seed)] for worker w, proved with one upload per proof."""
+        items = [(self.pinned[wi], self.inst[wi], seed) for wi, seed in jobs]
+        return self.pkg.feeder.prove_stream(self.plonk, self.ctxs[w], self.pks[w], self.streams[w], items)
 
-        def work(w):
+    def close(self):
+        if self.streams:
+            for s in self.streams:
+                s.free()
+        if self.pinned:
+            for p in self.pinned:
+                p.free()
+        for q in self.pks:
+            q.free()
+        self.params.free()
+        for cx in self.ctxs:
+            cx.close()
+
+
+class StubProver:
+    """TEST ONLY (AMDZK_BENCH_STUB=1, set by tests/test_bench_launcher.py, never by the driver): stands in for the
+    GPU so that the launcher, the rank plumbing, the barriers, the gather and the JSON line can be exercised on CPU
+    with gloo. Its "proofs" are hashes; the line it produces says data = "stub" and carries no roofline."""
+
+    def __init__(self, args, rank, local_rank, P, witness_seeds, want_host_srs):
+        self.P, self.K, self.n = P, 4, 16
+        self.desc = {"num_advice": 0, "lookups": [], "permutation_columns": [], "cs_degree": 3, "num_instance": 0, "num_fixed": 0}
+        self.witness_seeds = witness_seeds
+        self.setup_s = 0.0
+        self.streams = None
+
+    def prove(self, w, wi, seed):
+        time.sleep(0.002)
+        return (hashlib.sha256(b"stub-%d-%d" % (self.witness_seeds[wi], seed)).digest() * 3)[:96]
+
+    def sync(self):
+        pass
+
+    def check_affinity(self):
+        pass
+
+    def stream_setup(self):
+        self.streams = True
+
+    def prove_stream(self, w, jobs):
+        return [self.prove(w, wi, seed) for wi, seed in jobs]
+
+    def close(self):
+        pass
+
+
+def run_pool(P, jobs, fn):
+    """Run fn(worker, job) over `jobs` with up to P workers (worker w owns context w; ctypes drops the GIL inside the C
+    call, so the host drivers of different proofs overlap and their kernels interleave on the GPU). Results in job order."""
+    nxt = iter(range(len(jobs)))
+    lock = threading.Lock()
+    results = [None] * len(jobs)
+    errors = []
+
+    def work(w):
+        try:
             while True:
                 with lock:
                     i = next(nxt, None)
                 if i is None:
                     return
-                results[i] = plonk.create_proof(ctxs[w], pks[w], inst, d_adv, seed=1000 * rank + i)
+                results[i] = fn(w, jobs[i])
+        except BaseException as e:  # noqa: BLE001 - re-raised on the main thread
+            errors.append(e)
 
-        th = [threading.Thread(target=work, args=(w,)) for w in range(min(P, count))]
-        for t_ in th:
-            t_.start()
-        for t_ in th:
-            t_.join()
-        return [results[i] for i in range(first, first + count)]
+    th = [threading.Thread(target=work, args=(w,)) for w in range(min(P, max(1, len(jobs))))]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    if errors:
+        raise errors[0]
+    return results
 
-    def run_warmup(rounds):
-        """Untimed: `rounds` proofs on EVERY in-flight context (worker w -> context w), so that each proving
-        key's workspace, pinned staging and lazily loaded kernels are in steady state before the timed
-        region. (Warming only `rounds` contexts left the others to pay first-use costs inside the timing.)"""
-        def work(w):
-            for r in range(rounds):
-                plonk.create_proof(ctxs[w], pks[w], inst, d_adv, seed=1000 * rank + 500000 + r * P + w)
 
-        th = [threading.Thread(target=work, args=(w,)) for w in range(P)]
-        for t_ in th:
-            t_.start()
-        for t_ in th:
-            t_.join()
+# ------------------------------------------------------------------------------------------ one rank
+def run_rank(args):
+    stub = os.environ.get("AMDZK_BENCH_STUB") == "1"
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N`, or under "
+                         "torch.distributed.run with --nproc-per-node equal to --gpus)" % (args.gpus, world))
+    import torch
+    import torch.distributed as dist
 
-    torch.cuda.synchronize()
-    run_warmup(max(args.warmup, 0))
-    for cx in ctxs:
-        cx.sync()
-    torch.cuda.synchronize()
+    # AMDZK_BENCH_FORCE_DEVICE / AMDZK_BENCH_BACKEND exist only to rehearse the N>1 code path on a one-GPU box (all
+    # ranks on device 0, gloo instead of RCCL); the driver never sets them.
+    backend = os.environ.get("AMDZK_BENCH_BACKEND", "gloo" if stub else "nccl")
+    if not stub:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a gfx950 GPU (there is no CPU fallback in the product path)")
+        if os.environ.get("AMDZK_BENCH_FORCE_DEVICE") is not None:
+            local_rank = int(os.environ["AMDZK_BENCH_FORCE_DEVICE"])
+        torch.cuda.set_device(local_rank)
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    proofs = run_steps(0, args.steps)
-    for cx in ctxs:
-        cx.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+
+    steps = args.steps
+    if args.batch:
+        if args.batch % world:
+            raise SystemExit("bench.py: --batch %d is not a multiple of the %d ranks" % (args.batch, world))
+        steps = args.batch // world
+    P = args.concurrency
+    if P <= 0:
+        divs = [d for d in (4, 5, 3, 6) if steps % d == 0]  # 4 in flight measured best (profiles/r01e)
+        P = divs[0] if divs else min(4, max(1, steps))
+    # global proof index of (step s, rank r) = s*world + r (round-robin, batch.shard_indices). With --batch the witness
+    # of proof g has seed g; otherwise the rank cycles through nw witnesses of its own.
+    nw = args.witnesses or (steps if args.batch else min(4, steps))
+    nw = max(1, min(nw, steps))
+    if args.batch:
+        witness_seeds = [s * world + rank for s in range(nw)]
+    else:
+        witness_seeds = [7 + 1000 * rank + j for j in range(nw)]
+    want_cpu = rank == 0 and not args.no_cpu_baseline and not stub
+    prover = (StubProver if stub else GpuProver)(args, rank, local_rank, P, witness_seeds, want_cpu)
+    desc = prover.desc
+
+    jobs = [(s % nw, 1000 * rank + s) for s in range(steps)]  # (witness index, blinding seed)
+
+    def barrier():
+        prover.sync()
+        if world > 1:
+            dist.barrier()
+
+    def max_over_ranks(dt):
+        if world == 1:
+            return dt
         t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        # the one exchange step: every rank's proofs (equal length) gathered on all ranks over RCCL.
-        # global proof index = step*world + rank (round-robin, batch.shard_indices)
-        gathered = pkg.batch.gather_proofs(proofs, world * args.steps, device=coll_dev)
-        assert len(gathered) == world * args.steps and all(len(p) == len(proofs[0]) for p in gathered)
+        return float(t.item())
+
+    # untimed: W proofs on EVERY in-flight context, so that each proving key's workspace, pinned staging and lazily
+    # loaded kernels are in steady state before the timed region. (Per-context tasks: the JOB index is the context, so
+    # whichever thread picks a task up, no two tasks share a context.)
+    def warm_context(_, cx):
+        for r in range(max(args.warmup, 0)):
+            prover.prove(cx, (cx + r) % nw, 1000 * rank + 500000 + r * P + cx)
+
+    run_pool(P, list(range(P)), warm_context)
+    prover.check_affinity()
+    barrier()
+    t0 = time.perf_counter()
+    proofs = run_pool(P, jobs, lambda w, j: prover.prove(w, j[0], j[1]))
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    gathered_ok = None
+    if world > 1:
+        # the one exchange step: every rank's proofs (equal length) gathered on all ranks (RCCL all_gather)
+        if stub:
+            import __graft_entry__ as ge
+            batch_mod = ge.load_package().batch
+        else:
+            batch_mod = prover.pkg.batch
+        gathered = batch_mod.gather_proofs(proofs, world * steps, device=coll_dev)
+        gathered_ok = len(gathered) == world * steps and all(len(p) == len(proofs[0]) for p in gathered) and \
+            all(gathered[s * world + rank] == proofs[s] for s in range(steps))
+        if not gathered_ok:
+            raise SystemExit("bench.py: gathered proofs do not match this rank's proofs")
+
+    # PCIe-inclusive pass: the same steps, one witness upload per proof (double-buffered per context)
+    stream_rate = stream_equal = None
+    if not args.no_stream_pass:
+        prover.stream_setup()
+        per_worker = [[j for i, j in enumerate(jobs) if i % P == w] for w in range(P)]
+        run_pool(P, list(range(P)), lambda _, cx: prover.prove_stream(cx, per_worker[cx][:1]))  # untimed: buffers touched once
+        barrier()
+        t1 = time.perf_counter()
+        sp = run_pool(P, list(range(P)), lambda _, cx: prover.prove_stream(cx, per_worker[cx]))
+        barrier()
+        dts = max_over_ranks(time.perf_counter() - t1)
+        stream_rate = world * steps / dts
+        flat = {}
+        for w in range(P):
+            for (wi, seed), p in zip(per_worker[w], sp[w]):
+                flat[(wi, seed)] = p
+        stream_equal = all(flat[j] == p for j, p in zip(jobs, proofs))
+        if not stream_equal:
+            raise SystemExit("bench.py: proofs from streamed witnesses differ from the resident-witness proofs")
 
     roof = cpu = None
-    if rank == 0:
-        # per-kernel timing of one more proof with HIP events on the ctx stream
-        ctx.prof_reset()
-        ctx.prof_enable(True)
-        t1 = time.perf_counter()
-        step(10 ** 6)
-        wall_prof = (time.perf_counter() - t1) * 1e3
-        ctx.prof_enable(False)
-        prof = ctx.prof_dump()
-        dom_name = max(prof, key=lambda kname: prof[kname][1])
-        launches, total_ms = prof[dom_name]
-        gpu_ms = sum(v[1] for v in prof.values())
-        A, L, S = desc["num_advice"], len(desc["lookups"]), len(desc["permutation_columns"])
-        nsets = (S + desc["cs_degree"] - 3) // (desc["cs_degree"] - 2)
-        msm_cols = A + 2 * L + nsets + L + 1 + (desc["cs_degree"] - 1) + 2
-        npolys = A + desc["num_instance"] + 3 * L + nsets
-        if dom_name.startswith("msm"):
-            # algorithmic bytes of an MSM = 96 B per (scalar, base) pair; this kernel's
-            # launches cover all msm_cols committed columns of the proof
-            alg_bytes = 96.0 * n * msm_cols / launches
-        elif dom_name.startswith("ntt"):
-            alg_bytes = 64.0 * (n * npolys + (n << 2) * npolys + (n << 2)) / launches
-        else:  # h(X) evaluation: every coset column read once + h written
-            alg_bytes = 32.0 * (n << 2) * (npolys + desc["num_fixed"] + S + 4 + 1) / launches
-        avg_s = total_ms / launches * 1e-3
-        traffic, traffic_src = pmc_traffic(dom_name)
-        roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(alg_bytes / avg_s / 1e9, 3), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 6), "traffic": traffic,
-                "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(alg_bytes),
-                "avg_launch_ms": round(total_ms / launches, 4), "launches_per_step": launches,
-                "gpu_busy_ms_per_step": round(gpu_ms, 3), "wall_ms_profiled_step": round(wall_prof, 3),
-                "per_kernel_ms": {kname: round(v[1], 3) for kname, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
+    wall_prof = None
+    if rank == 0 and not stub:
+        roof, wall_prof = roofline(prover, desc)
         if not args.no_cpu_baseline:
-            gpu_proof = plonk.create_proof(ctx, pk, inst, d_adv, seed=424242)
-            cpu = cpu_baseline(c, s_int, tr_int, params, gpu_proof)
+            gpu_proof = prover.prove(0, 0, 424242)
+            cpu = cpu_baseline(prover, gpu_proof)
 
     if rank == 0:
-        ms = dt / args.steps * 1e3
-        line = {"metric": "create_proof wall-clock (ms) + proofs/sec, full Aadhaar circuit, 1/2/4/8 GPU" if args.shape == "full"
-                else "create_proof wall-clock (ms) + proofs/sec, RSA-SHA256 circuit shape",
-                "value": round(world * args.steps / dt, 4), "unit": "proofs/s", "n_gpus": world, "steps": args.steps,
+        ms = dt / steps * 1e3
+        metric = "create_proof wall-clock (ms) + proofs/sec, full Aadhaar circuit, 1/2/4/8 GPU" if args.shape == "full" \
+            else "create_proof wall-clock (ms) + proofs/sec, RSA-SHA256 circuit shape"
+        line = {"metric": ("STUB " if stub else "") + metric,
+                "value": round(world * steps / dt, 4), "unit": "proofs/s", "n_gpus": world, "steps": steps,
                 "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "u32 limbs (254-bit Montgomery integers: 9 x 29-bit in the hot products, 8 x 32-bit elsewhere)", "data": "synthetic",
-                "config": {"workload": "create_proof, %s %s: %d advice, %d lookups, %d permutation columns, degree %d, "
-                                       "KZG/SHPLONK/Blake2b, witness resident"
-                                       % (make_circuit.__name__, args.shape, desc["num_advice"], len(desc["lookups"]), len(desc["permutation_columns"]), desc["cs_degree"]),
-                           "k": K, "extended_k": K + 2, "proof_bytes": len(proofs[-1]), "proofs_in_flight_per_gpu": P,
+                "vs_baseline": None,
+                "dtype": "u32 limbs (254-bit Montgomery integers: 9 x 29-bit in the hot products, 8 x 32-bit elsewhere)",
+                "data": "stub" if stub else "synthetic",
+                "config": {"workload": "create_proof, %s: %d advice, %d lookups, %d permutation columns, degree %d, "
+                                       "KZG/SHPLONK/Blake2b, %d distinct witnesses per GPU resident in HBM"
+                                       % (args.shape, desc["num_advice"], len(desc["lookups"]), len(desc["permutation_columns"]),
+                                          desc["cs_degree"], nw),
+                           "k": prover.K, "extended_k": prover.K + 2, "proof_bytes": len(proofs[-1]), "proofs_in_flight_per_gpu": P,
+                           "batch": args.batch or None, "proofs_total": world * steps,
                            "warmup_proofs_untimed": max(args.warmup, 0) * P,
-                           "single_proof_latency_ms": round(wall_prof, 3) if rank == 0 else None,
+                           "single_proof_latency_ms": round(wall_prof, 3) if wall_prof else None,
+                           "pcie_inclusive_proofs_per_s": round(stream_rate, 4) if stream_rate else None,
+                           "pcie_inclusive_note": "same steps with one %.0f MiB witness upload per proof from pinned host memory on a copy "
+                                                  "stream, double-buffered per in-flight context; proofs byte-equal to the resident run"
+                                                  % (desc["num_advice"] * prover.n * 32 / 2 ** 20) if stream_rate else None,
+                           "gather": ("all_gather of %d proofs, every rank's own proofs found in place" % (world * steps)) if gathered_ok else None,
                            "parallelism": "independent proofs sharded across GPUs, %d in flight per GPU" % P,
-                           "setup_s_excluded": round(t_setup, 1)},
+                           "setup_s_excluded": round(prover.setup_s, 1)},
                 "roofline": roof, "cpu_baseline": cpu}
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
-    for q in pks:
-        q.free()
-    params.free()
-    for cx in ctxs:
-        cx.close()
+    prover.close()
+    if cpu is not None and not cpu["proof_bytes_equal_gpu"]:
+        raise SystemExit("bench.py: the CPU oracle's proof differs from the GPU's at the benchmarked shape")
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same
-    command (profiles/r01v_kernel_summary.csv; counters cannot be read from inside the process).
-    FETCH_SIZE + WRITE_SIZE in KiB; the gfx950 x2 FETCH correction is for wide coalesced streams and is
-    NOT applied to this kernel's 64-byte random gathers (uncalibrated pattern, stated as such)."""
-    names = {"msm_accum_l1": "msm_accum_seg_kernel<true>", "expr_evaluate_h": "expr_eval_kernel"}
-    path = os.path.join(ROOT, "profiles", "r01v_kernel_summary.csv")
-    try:
-        import csv
-        for row in csv.DictReader(open(path)):
-            if row["kernel"] == names.get(kernel) and row["FETCH_SIZE_KiB_per_launch_raw"]:
-                b = (float(row["FETCH_SIZE_KiB_per_launch_raw"]) + float(row["WRITE_SIZE_KiB_per_launch_raw"])) * 1024
-                return round(b), "profiles/r01v_kernel_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, raw, per launch)"
-    except OSError:
-        pass
-    return None, None
+def roofline(prover, desc):
+    """Per-kernel timing of one more proof with HIP events on the ctx stream (the stream the kernels run on)."""
+    ctx = prover.ctx
+    n = prover.n
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    t1 = time.perf_counter()
+    prover.prove(0, 0, 10 ** 6)
+    wall_prof = (time.perf_counter() - t1) * 1e3
+    ctx.prof_enable(False)
+    prof = ctx.prof_dump()
+    dom_name = max(prof, key=lambda kname: prof[kname][1])
+    launches, total_ms = prof[dom_name]
+    gpu_ms = sum(v[1] for v in prof.values())
+    A, L, S = desc["num_advice"], len(desc["lookups"]), len(desc["permutation_columns"])
+    nsets = (S + desc["cs_degree"] - 3) // (desc["cs_degree"] - 2)
+    msm_cols = A + 2 * L + nsets + L + 1 + (desc["cs_degree"] - 1) + 2
+    npolys = A + desc["num_instance"] + 3 * L + nsets
+    if dom_name.startswith("msm"):
+        # algorithmic bytes of an MSM = 96 B per (scalar, base) pair; this kernel's launches cover all
+        # msm_cols committed columns of the proof
+        alg_bytes = 96.0 * n * msm_cols / launches
+    elif dom_name.startswith("ntt"):
+        alg_bytes = 64.0 * (n * npolys + (n << 2) * npolys + (n << 2)) / launches
+    else:  # h(X) evaluation: every coset column read once + h written
+        alg_bytes = 32.0 * (n << 2) * (npolys + desc["num_fixed"] + S + 4 + 1) / launches
+    avg_s = total_ms / launches * 1e-3
+    pmc = pmc_counters(dom_name)
+    roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(alg_bytes / avg_s / 1e9, 3), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 6), "traffic": pmc.get("traffic"),
+            "traffic_source": pmc.get("source"), "algorithmic_bytes_per_launch": round(alg_bytes),
+            "avg_launch_ms": round(total_ms / launches, 4), "launches_per_step": launches,
+            # what the kernel is actually limited by: VALU issue. cycles per VALU wave-instruction =
+            # launch time x 1024 SIMDs x 2.4 GHz / SQ_INSTS_VALU per launch; ~5 means the SIMDs issue back to back
+            # (v_mad_u64_u32 takes 5.3 cycles, plain VALU 2.7: profiles/r01f_microbench.jsonl)
+            "valu_wave_insts_per_launch": pmc.get("valu"),
+            "valu_issue_cycles_per_inst": round(avg_s * 1024 * 2.4e9 / pmc["valu"], 2) if pmc.get("valu") else None,
+            "gpu_busy_ms_per_step": round(gpu_ms, 3), "wall_ms_profiled_step": round(wall_prof, 3),
+            "per_kernel_ms": {kname: round(v[1], 3) for kname, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
+    return roof, wall_prof
 
 
-def cpu_baseline(c, s_int, tr_int, params, gpu_proof):
-    """CPU leg: ONE full create_proof of the same circuit, witness, SRS and RNG seed on the host cores
-    with the oracle prover (oracle/plonk_fast.py: upstream's step order; every O(n) loop — Pippenger MSM
-    per commitment as halo2's best_multiexp, radix-2 FFTs, the h(X) evaluation, permutation / lookup
-    products, evaluations — in the C++ oracle under OpenMP; transcript, RNG and glue in Python, which
-    inflates the CPU time somewhat). Its proof must equal the GPU's byte for byte; keygen is excluded on
-    both sides. The oracle is the measured baseline here, never the product path."""
+def kernel_src_hash():
+    """sha256 over the kernel sources (csrc/*.hip, *.cuh, *.hpp), the same way tools/summarize_prof.py stamps a PMC
+    summary: counters measured on other kernel code are not this build's counters."""
+    import glob
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "anon-aadhaar-halo2_amd", "csrc")
+    for p in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.cuh")) + glob.glob(os.path.join(d, "*.hpp"))):
+        h.update(os.path.basename(p).encode() + b"\0")
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_counters(kernel):
+    """HBM bytes and VALU wave-instructions per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    of this same command (counters cannot be read from inside the process): the newest profiles/*_kernel_summary.csv
+    whose first line records THIS build's kernel-source hash. A summary taken on other kernel code is refused and the
+    fields stay null. FETCH_SIZE + WRITE_SIZE in KiB; the gfx950 x2 FETCH correction is for wide coalesced streams and
+    is NOT applied to this kernel's 64-byte random gathers (uncalibrated pattern, stated as such)."""
+    import csv
+    import glob
+    names = {"msm_accum_l1": "msm_accum_seg_kernel<true>", "expr_evaluate_h": "expr_eval_kernel<true>",
+             "ntt_step": "ntt_step_kernel<false>", "ntt_step_last": "ntt_step_kernel<true>"}
+    want = kernel_src_hash()
+    stale = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_summary.csv")), reverse=True):
+        try:
+            with open(path) as f:
+                first = f.readline()
+                if not first.startswith("# kernel_src_sha256="):
+                    continue
+                if first.strip().split("=", 1)[1] != want:
+                    stale = stale or os.path.basename(path)
+                    continue
+                for row in csv.DictReader(f):
+                    if row["kernel"] == names.get(kernel, kernel):
+                        out = {"source": "profiles/%s (rocprofv3 --pmc, raw, per launch; kernel sources %s)" % (os.path.basename(path), want)}
+                        if row.get("FETCH_SIZE_KiB_per_launch_raw") and row.get("WRITE_SIZE_KiB_per_launch_raw"):
+                            out["traffic"] = round((float(row["FETCH_SIZE_KiB_per_launch_raw"]) + float(row["WRITE_SIZE_KiB_per_launch_raw"])) * 1024)
+                        if row.get("SQ_INSTS_VALU_per_launch"):
+                            out["valu"] = round(float(row["SQ_INSTS_VALU_per_launch"]))
+                        return out
+        except OSError:
+            continue
+    return {"source": "none for kernel sources %s%s" % (want, " (newest stamped summary, %s, is of other sources: refused)" % stale if stale else "")}
+
+
+def cpu_baseline(prover, gpu_proof):
+    """CPU leg: ONE full create_proof of the same circuit, witness, SRS and RNG seed on the host cores with the oracle
+    prover (oracle/plonk_fast.py: upstream's step order; every O(n) loop — Pippenger MSM per commitment as halo2's
+    best_multiexp, radix-2 FFTs, the h(X) evaluation, permutation / lookup products, evaluations — in the C++ oracle under
+    OpenMP; transcript, RNG and glue in Python, which inflates the CPU time somewhat). Its proof must equal the GPU's byte
+    for byte (bench.py exits non-zero otherwise); keygen is excluded on both sides. The oracle is the measured baseline
+    here, never the product path."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import plonk_fast as PF
 
+    c = prover.circuit
+    advice, instances = prover.witness_ints[0]
     t0 = time.perf_counter()
-    fpk = PF.FastKey(c.desc, c.fixed, c.assembly.mapping, s_int, tr_int, msm_bases=(params._g, params._gl))
+    fpk = PF.FastKey(c.desc, c.fixed, c.assembly.mapping, prover.s_int, prover.tr_int, msm_bases=(prover.params._g, prover.params._gl))
     t_keygen = time.perf_counter() - t0
     t0 = time.perf_counter()
-    proof = PF.create_proof(fpk, c.instances, c.advice, seed=424242)
+    proof = PF.create_proof(fpk, instances, advice, seed=424242)
     dt = time.perf_counter() - t0
     return {"value": round(1.0 / dt, 5), "unit": "proofs/s", "cores": PF.threads(), "kind": "port",
             "sample": "1 full create_proof (same circuit/witness/SRS/seed as the GPU run) with the C++/OpenMP oracle prover, "
                       "%d threads; Python transcript/RNG/glue included; keygen (%.0f s) excluded" % (PF.threads(), t_keygen),
             "seconds_per_proof": round(dt, 2), "proof_bytes_equal_gpu": proof == gpu_proof}
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # parent of N ranks: nothing here has imported torch or loaded libamdzk
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else list(argv)))
+    run_rank(args)
 
 
 if __name__ == "__main__":

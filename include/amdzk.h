@@ -62,6 +62,14 @@ int amdzk_version(void);
 /* Run subsequent work of this ctx on an existing hipStream_t (e.g. torch's current stream);
  * NULL restores the ctx's own stream. */
 int amdzk_set_stream(amdzk_ctx* ctx, void* hip_stream);
+/* HIP's current device is per host thread; a ctx belongs to ONE device. Every entry point below pins the calling
+ * thread to the ctx's device for the duration of the call and restores the caller's device afterwards, so a ctx
+ * may be created on one thread and used from another (one call at a time). amdzk_ctx_device returns that device;
+ * the *_check_affinity calls verify that the ctx's stream, workspaces and tables / a pointer / a proving key's
+ * buffers really live there (AMDZK_E_INVALID with a message otherwise) — a cheap assertion for multi-GPU hosts. */
+int amdzk_ctx_device(const amdzk_ctx* ctx);
+int amdzk_ctx_check_affinity(amdzk_ctx* ctx);
+int amdzk_ptr_check_affinity(amdzk_ctx* ctx, const void* dptr);
 int amdzk_sync(amdzk_ctx* ctx);
 
 /* ---- device memory (plain hipMalloc'd bytes; any device pointer of the same GPU is accepted by
@@ -71,6 +79,17 @@ int amdzk_dev_free(amdzk_ctx* ctx, void* dptr);
 int amdzk_dev_upload(amdzk_ctx* ctx, void* dptr, const void* host, size_t bytes);
 int amdzk_dev_download(amdzk_ctx* ctx, void* host, const void* dptr, size_t bytes);
 int amdzk_dev_memset(amdzk_ctx* ctx, void* dptr, int byte, size_t bytes);
+/* Streaming one witness per proof (what a caller of create_proof after Circuit::synthesize,
+ * /root/reference/src/lib.rs:328-397, does): synthesize into pinned host memory (amdzk_host_alloc), start the
+ * upload of the NEXT proof's witness with amdzk_dev_upload_async — it runs on a second HIP stream of the ctx,
+ * beside the kernels of the proof in progress — and call amdzk_upload_fence before the create_proof that reads
+ * it: work submitted to the ctx after the fence waits (on the device, not on the host) for every upload issued
+ * before it. The source of an asynchronous upload must stay untouched until a fence + amdzk_sync, or the
+ * create_proof that follows the fence, has returned. */
+int amdzk_host_alloc(amdzk_ctx* ctx, size_t bytes, void** hptr);
+int amdzk_host_free(amdzk_ctx* ctx, void* hptr);
+int amdzk_dev_upload_async(amdzk_ctx* ctx, void* dptr, const void* host, size_t bytes);
+int amdzk_upload_fence(amdzk_ctx* ctx);
 
 /* ---- SRS: replaces the resident part of poly::kzg::commitment::ParamsKZG {g, g_lagrange} [UP]
  * g, g_lagrange: n = 2^k G1Affine each (either may be NULL if that basis is never used).
@@ -195,6 +214,7 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* circ
                  const uint64_t* fixed_values, const uint32_t* perm_mapping,
                  const uint64_t transcript_repr[4], amdzk_pk** out);
 void amdzk_pk_free(amdzk_ctx* ctx, amdzk_pk* pk);
+int amdzk_pk_check_affinity(amdzk_ctx* ctx, const amdzk_pk* pk);
 /* VerifyingKey commitments: fixed columns (num_fixed x G1Affine), permutation (num_perm_columns x G1Affine). */
 int amdzk_pk_commitments(const amdzk_pk* pk, uint64_t* fixed_out, uint64_t* perm_out);
 /* instances[c]: instance_lens[c] public inputs of instance column c (host). d_advice: num_advice

@@ -42,6 +42,23 @@ def test_msm_uniform_matches_oracle(ctx, pkg, oracle, srs14, k):
     params.free()
 
 
+@pytest.mark.parametrize("k", [15, 17, 18])
+def test_msm_prover_sizes_match_oracle(ctx, pkg, oracle, k):
+    """Every window width the prover selects for the BASELINE configurations (c = 13 at k = 15, c = 14 at k = 17 and
+    18: msm.hip pick_window_bits) checked directly against the oracle's Pippenger: uniform scalars, a witness-like
+    skewed column, and a short (ragged) column, in one batched call over the Lagrange basis."""
+    n = 1 << k
+    g = oracle.srs_powers(zu.fr_from_int(0x5EED0000 + k), n)
+    params = pkg.kzg.ParamsKZG(ctx, k, g_lagrange=g)
+    cols = [zu.random_fr(n, seed=900 + k), zu.skewed_fr(n, 910 + k, oracle)]
+    got = pkg.arithmetic.best_multiexp_batch(ctx, params.h, 1, cols)
+    for c in range(2):
+        assert np.array_equal(zu.jac_to_affine_host(oracle, got[c]), oracle.best_multiexp(cols[c], g))
+    short = zu.random_fr(n - 12345, seed=920 + k)
+    check(ctx, pkg, oracle, params, g, short, basis=1)
+    params.free()
+
+
 def test_msm_edge_cases(ctx, pkg, oracle, srs14):
     k = 10
     n = 1 << k

@@ -114,6 +114,35 @@ def test_rsa_sha256_shape_k15_bytes_equal_cpu_prover_and_verify(ctx, pkg, plonk,
     d_adv.free(); pk.free(); params.free()
 
 
+def test_rsa_sha256_shape_k18_bytes_equal_cpu_prover_and_verify(ctx, pkg, plonk, oracle):
+    """BASELINE config 2 at its stated k ~ 18: the RSA-SHA256 shape re-configured to k = 18 (same area, 8x fewer gate
+    columns: workloads.SHAPES["k18"]; shape source /root/reference/src/lib.rs:263-274). Different window width
+    (c = 14), 3-step NTT at 2^20, larger workspaces than any k = 15 test. The SRS is built on the device
+    (amdzk_srs_setup, itself checked against the oracle in test_gpu_msm.py) and handed to the CPU oracle prover; one
+    seed — the CPU proof at this size takes the better part of a minute."""
+    import plonk_fast as PF
+
+    shape = dict(circuits.SHAPES["k18"])
+    c = circuits.rsa_sha256_shape(plonk, **shape)
+    assert c.k == 18 and c.desc["num_advice"] == 14 and len(c.desc["lookups"]) == 3
+    circuits.check_satisfied(c, rows=range(0, c.usable, 7919))
+    params = pkg.kzg.ParamsKZG.setup(ctx, c.k, zu.fr_from_int(TAU), want_host_copy=True)
+    fixed = np.stack([zu.ints_to_fr(oracle, col) for col in c.fixed])
+    pk = plonk.ProvingKey(ctx, params, c.desc, fixed, c.assembly.mapping, zu.fr_from_int(123456789))
+    adv = np.stack([zu.ints_to_fr(oracle, col) for col in c.advice])
+    d_adv = ctx.alloc(adv.nbytes).upload(adv)
+    inst = [zu.ints_to_fr(oracle, col) if col else np.zeros((0, 4), np.uint64) for col in c.instances]
+    proof = plonk.create_proof(ctx, pk, inst, d_adv, seed=1818)
+    assert len(proof) == plonk.proof_size(ctx, pk)
+    fpk = PF.FastKey(c.desc, c.fixed, c.assembly.mapping, TAU, 123456789, msm_bases=(params._g, params._gl))
+    f, p = pk.commitments()
+    assert [zu.point_to_ints(x) for x in f] == fpk.fixed_commitments
+    assert [zu.point_to_ints(x) for x in p] == fpk.permutation_commitments
+    assert proof == PF.create_proof(fpk, c.instances, c.advice, seed=1818)
+    assert PR.verify_proof(vk_from_device(pk, c), c.instances, proof)
+    d_adv.free(); pk.free(); params.free()
+
+
 def test_full_aadhaar_shape_equals_oracle(ctx, pkg, plonk, oracle):
     """Composite AadhaarQRVerifierCircuit budget (/root/reference/src/aadhaar_verifier_circuit.rs:49-56,
     BASELINE config 3): RSA shape + IdentityCircuit gates + 7 never-queried timestamp columns +
