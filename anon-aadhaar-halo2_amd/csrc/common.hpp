@@ -134,6 +134,18 @@ void zk_prof_drain(amdzk_ctx* ctx);
     ZK_HIP(ctx, hipGetLastError());                                                  \
   } while (0)
 
+// Optional per-element multiplier tables of zk_ntt_ex (ntt.hip): entries are constants in radix 2^261 (packed
+// canonical), one per element of a column. nz > 1 runs nz transforms of every input column, transform z with the
+// tables at + z * tab_z_stride and its output at + z * out_z_stride (the cosets of the quotient domain, poly.hip).
+struct NttTables {
+  const bn254::Fr* in_tab = nullptr;   // input element i *= in_tab[i]
+  const bn254::Fr* out_tab = nullptr;  // output element j *= out_tab[j]
+  size_t tab_col_stride = 0;           // elements the tables advance per column
+  size_t tab_z_stride = 0;             // ... and per z
+  uint32_t nz = 1;
+  size_t out_z_stride = 0;
+};
+
 // entry points implemented in the kernel translation units
 int zk_ntt_dev(amdzk_ctx* ctx, bn254::Fr* d_a, uint32_t log_n, const uint64_t omega[4],
                uint32_t flags, size_t ncols, size_t col_stride);

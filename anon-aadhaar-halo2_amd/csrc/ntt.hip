@@ -52,11 +52,21 @@ struct NttPassArgs {
   Fr in_c[2];             // first step, IN_COSET: element i is multiplied by in_c[i%3 - 1] when i%3 != 0   (radix 2^261)
   Fr out_c[3];            // last step, OUT_MUL: element j is multiplied by out_c[j%3]                       (radix 2^261)
   Fr in_c0;               // first step, IN_ALL: elements with i%3 == 0 are multiplied too (a global input factor)
+  // Per-element multiplier tables (radix 2^261, packed canonical), one entry per element of a column: F_IN_TABLE
+  // multiplies input element i by in_tab[i] in the first step, F_OUT_TABLE output element j by out_tab[j] in the last.
+  // blockIdx.z selects one of several transforms of the SAME input column with different tables (the cosets of
+  // the quotient domain, poly.hip): tables and outputs advance by *_z_stride per z, tables by tab_col_stride per column.
+  const Fr* in_tab;
+  const Fr* out_tab;
+  size_t tab_col_stride, tab_z_stride;
+  size_t in_z_stride, out_z_stride;
 };
 
 constexpr uint32_t F_IN_COSET = 1u;
 constexpr uint32_t F_OUT_MUL = 2u;
 constexpr uint32_t F_IN_ALL = 4u;
+constexpr uint32_t F_IN_TABLE = 8u;
+constexpr uint32_t F_OUT_TABLE = 16u;
 
 __device__ __forceinline__ uint32_t brev(uint32_t x, uint32_t bits) {
   return bits == 0 ? 0u : (__brev(x) >> (32 - bits));
@@ -112,8 +122,10 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
   const uint32_t tile = rows << a.log_c;
   uint32_t* TW = L + (size_t)tile * 9;  // rows/2 sub-transform twiddles omega_{n_p}^i (radix 2^261), as limbs
   const uint32_t tile_id = blockIdx.x;
-  const Fr* in = a.in + (size_t)blockIdx.y * a.in_col_stride;
-  Fr* out = a.out + (size_t)blockIdx.y * a.out_col_stride;
+  const Fr* in = a.in + (size_t)blockIdx.y * a.in_col_stride + (size_t)blockIdx.z * a.in_z_stride;
+  Fr* out = a.out + (size_t)blockIdx.y * a.out_col_stride + (size_t)blockIdx.z * a.out_z_stride;
+  const size_t tab_off = (size_t)blockIdx.y * a.tab_col_stride + (size_t)blockIdx.z * a.tab_z_stride;
+  const bool in_table = a.pass == 0 && (a.flags & F_IN_TABLE);
   const uint32_t log_n = a.log_n;
 
   // ---- stage the sub-transform twiddles: omega_{n_p}^i = omega^(i * n/n_p)
@@ -134,7 +146,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
       const size_t gi = in_base + (size_t)x * row_stride + c;
       Fr v = Fr::zero();
       if (a.pass != 0 || gi < a.in_len) v = ld_fr(in + gi);
-      lds_st(L, e, fr29_unpack(v));
+      Fr29 xv = fr29_unpack(v);
+      if (in_table && gi < a.in_len) xv = f29_mul(xv, fr29_unpack(ld_fr(a.in_tab + tab_off + gi)));
+      lds_st(L, e, xv);
     }
   } else {
     // rows of the tile are C consecutive values of j1 (the fastest output digit)
@@ -152,7 +166,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
       const size_t gi = in_base + (size_t)rr * row_stride + x;
       Fr v = Fr::zero();
       if (a.pass != 0 || gi < a.in_len) v = ld_fr(in + gi);
-      lds_st(L, (x << a.log_c) + rr, fr29_unpack(v));
+      Fr29 xv = fr29_unpack(v);
+      if (in_table && gi < a.in_len) xv = f29_mul(xv, fr29_unpack(ld_fr(a.in_tab + tab_off + gi)));
+      lds_st(L, (x << a.log_c) + rr, xv);
     }
   }
   __syncthreads();
@@ -216,7 +232,9 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
       uint32_t j = e >> a.log_c, rr = e & (C - 1);
       Fr29 x = lds_ld(L, (brev(j, a.s) << a.log_c) + rr);
       size_t oi = out_base + rr + ((size_t)j << log_ostride);
-      if (a.flags & F_OUT_MUL) {
+      if (a.flags & F_OUT_TABLE) {
+        x = f29_mul(x, fr29_unpack(ld_fr(a.out_tab + tab_off + oi)));
+      } else if (a.flags & F_OUT_MUL) {
         const uint32_t m = (uint32_t)(oi % 3);
         x = f29_mul(x, m == 0 ? oc0 : m == 1 ? oc1 : oc2);
       } else {
@@ -304,8 +322,10 @@ Plan make_plan(uint32_t log_n, uint32_t tile_log) {
 //   in_len   : number of valid input elements per column (rest read as zero); 0 means n.
 //   in_coset : if non-null, 2 constants applied to input element i with i%3 = 1, 2
 //   out_mul  : if non-null, 3 constants applied to output element j by j%3
+//   tabs     : per-element multiplier tables and the z dimension (NttTables, common.hpp); null = none
 int zk_ntt_ex(amdzk_ctx* ctx, const Fr* d_in, size_t in_stride, Fr* d_out, size_t out_stride, uint32_t log_n,
-              const uint64_t omega[4], size_t ncols, uint32_t in_len, const Fr* in_coset, const Fr* out_mul, const Fr* in_first) {
+              const uint64_t omega[4], size_t ncols, uint32_t in_len, const Fr* in_coset, const Fr* out_mul, const Fr* in_first,
+              const NttTables* tabs) {
   if (log_n > 27) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "ntt: log_n %u > 27", log_n);
   if (ncols == 0) return AMDZK_OK;
   const size_t n = (size_t)1 << log_n;
@@ -317,8 +337,11 @@ int zk_ntt_ex(amdzk_ctx* ctx, const Fr* d_in, size_t in_stride, Fr* d_out, size_
   const uint32_t tile_log = env_u32("AMDZK_NTT_TILE_LOG", 10);
   Plan plan = make_plan(log_n, tile_log);
 
+  const uint32_t nz = tabs && tabs->nz ? tabs->nz : 1;
+  if (nz > 1 && (in_coset || out_mul)) ZK_FAIL(ctx, AMDZK_E_INVALID, "ntt: the z dimension goes with multiplier tables only");
+  if (nz > 65535) ZK_FAIL(ctx, AMDZK_E_INVALID, "ntt: nz too large");
   Fr* ws = nullptr;
-  if (plan.npass > 1) ZK_TRY(zk_ws_reserve(ctx, 0, ncols * n * sizeof(Fr), (void**)&ws));
+  if (plan.npass > 1) ZK_TRY(zk_ws_reserve(ctx, 0, ncols * nz * n * sizeof(Fr), (void**)&ws));
 
   NttPassArgs a;
   memset(&a, 0, sizeof(a));
@@ -362,12 +385,23 @@ int zk_ntt_ex(amdzk_ctx* ctx, const Fr* d_in, size_t in_stride, Fr* d_out, size_
     // first step reads the caller's input, last step writes the caller's output, the workspace
     // carries the intermediate layout. A single-step transform covers a column with one tile (all
     // loads precede all stores), so it may run in place.
+    // the workspace holds [column][z][n]; the caller's input is shared by all z, its output advances by out_z_stride
     a.in = (p == 0) ? d_in : ws;
-    a.in_col_stride = (p == 0) ? in_stride : n;
+    a.in_col_stride = (p == 0) ? in_stride : (size_t)nz * n;
+    a.in_z_stride = (p == 0) ? 0 : n;
     a.out = last ? d_out : ws;
-    a.out_col_stride = last ? out_stride : n;
+    a.out_col_stride = last ? out_stride : (size_t)nz * n;
+    a.out_z_stride = last ? (tabs ? tabs->out_z_stride : 0) : n;
+    if (tabs) {
+      a.in_tab = tabs->in_tab;
+      a.out_tab = tabs->out_tab;
+      a.tab_col_stride = tabs->tab_col_stride;
+      a.tab_z_stride = tabs->tab_z_stride;
+      if (p == 0 && tabs->in_tab) a.flags |= F_IN_TABLE;
+      if (last && tabs->out_tab) a.flags |= F_OUT_TABLE;
+    }
     const uint32_t tile_elems_log = a.s + a.log_c;
-    dim3 grid((uint32_t)(n >> tile_elems_log), (uint32_t)ncols), block(NTT_THREADS);
+    dim3 grid((uint32_t)(n >> tile_elems_log), (uint32_t)ncols, nz), block(NTT_THREADS);
     size_t shmem = (((size_t)1 << tile_elems_log) + ((size_t)1 << a.s) / 2 + 1) * 9 * sizeof(uint32_t);  // limbs, see ntt_step_kernel
     if (last) {
       if (shmem > 65536) ZK_HIP(ctx, hipFuncSetAttribute((const void*)ntt_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -391,7 +425,7 @@ int zk_ntt_dev(amdzk_ctx* ctx, Fr* d_a, uint32_t log_n, const uint64_t omega[4],
   if (flags & AMDZK_NTT_SCALE_NINV) {
     Fr ninv = zk_fr_inv_pow2(log_n);
     Fr oc[3] = {ninv, ninv, ninv};
-    return zk_ntt_ex(ctx, d_a, col_stride, d_a, col_stride, log_n, omega, ncols, 0, nullptr, oc, nullptr);
+    return zk_ntt_ex(ctx, d_a, col_stride, d_a, col_stride, log_n, omega, ncols, 0, nullptr, oc, nullptr, nullptr);
   }
-  return zk_ntt_ex(ctx, d_a, col_stride, d_a, col_stride, log_n, omega, ncols, 0, nullptr, nullptr, nullptr);
+  return zk_ntt_ex(ctx, d_a, col_stride, d_a, col_stride, log_n, omega, ncols, 0, nullptr, nullptr, nullptr, nullptr);
 }

@@ -66,8 +66,11 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_kernel(ExprArgs a) {
   // Software pipeline over the (wave-uniform) instruction stream: while instruction pc executes, the
   // operand of pc+1 is in flight (vector load) and instruction pc+2 is being fetched (scalar load).
   const ExprInstr nop{0u, 0, nullptr};
+  // rows come in blocks of mask + 1 = n (one block in the Lagrange domain, one per coset in the quotient domain):
+  // a rotation wraps inside the row's own block
+  const size_t blk_base = row & ~a.mask;
   auto fetch = [&](const ExprInstr& in) -> Fr {
-    const size_t idx = (row + (size_t)(int64_t)in.rot) & a.mask;
+    const size_t idx = blk_base + ((row + (size_t)(int64_t)in.rot) & a.mask);
     return ld_fr(in.ptr + idx);
   };
   ExprInstr cur = a.prog_len > 0 ? a.prog[0] : nop;

@@ -43,7 +43,7 @@ struct ExprArgs {
   const bn254::Fr* const* cols;  // slot -> column base (device array of device pointers); used for the hot slots
   bn254::Fr* const* outs;        // OP_STORE targets
   bn254::Fr* h_out;              // OP_ACC result per row (may be null)
-  size_t mask;                   // rows - 1
+  size_t mask;                   // n - 1: rotations wrap inside blocks of n rows (nrows = n, or nc * n in the quotient domain)
   size_t nrows;
   const bn254::Fr* y_ptr;        // y (OP_ACC)
   uint32_t hot[EXPR_HOT];        // column slots held in registers for the whole row (rotation 0), or EXPR_NO_SLOT

@@ -15,7 +15,8 @@
 using namespace bn254;
 
 int zk_ntt_ex(amdzk_ctx* ctx, const Fr* d_in, size_t in_stride, Fr* d_out, size_t out_stride, uint32_t log_n,
-              const uint64_t omega[4], size_t ncols, uint32_t in_len, const Fr* in_coset, const Fr* out_mul, const Fr* in_first);
+              const uint64_t omega[4], size_t ncols, uint32_t in_len, const Fr* in_coset, const Fr* out_mul, const Fr* in_first,
+              const NttTables* tabs);
 Fr zk_fr_inv_pow2(uint32_t log_n);
 
 struct amdzk_domain {
@@ -26,6 +27,14 @@ struct amdzk_domain {
   Fr ifft_divisor, extended_ifft_divisor;
   std::vector<Fr> t_evaluations;      // already inverted, length 2^(extended_k - k)
   Fr* d_t_evaluations = nullptr;
+  // Quotient plan (prover-private, zk_quotient_plan): the h(X) numerator is evaluated on nc cosets g_c * H of the
+  // size-n subgroup H, g_c = zeta * extended_omega^c — the first nc of the 2^(extended_k - k) cosets that make up
+  // upstream's extended domain (extended index j = c + 2^(ek-k) * i  <->  coset c, row i).
+  uint32_t nc = 0;
+  Fr* d_coset_in = nullptr;    // [nc][n]  32 * g_c^m                              (radix 2^261 constants)
+  Fr* d_coset_out = nullptr;   // [nc][n]  g_c^-m / (32 * n * (g_c^n - 1))         (radix 2^261 constants)
+  std::vector<Fr> coset_g;     // g_c
+  std::vector<Fr> vinv;        // [nc][nc] inverse of V[c][j] = (g_c^n)^j, row-major [j][c]
 };
 
 namespace {
@@ -71,6 +80,37 @@ __global__ __launch_bounds__(256) void mul_periodic_kernel(Fr* a, size_t col_str
 __global__ __launch_bounds__(256) void mul_const_kernel(Fr* a, size_t n, Fr c) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     st_fr(a + i, fr29_mul_std(ld_fr(a + i), c));
+}
+
+// tab[m] = scale * g^m as a radix-2^261 constant (packed canonical), m < count. Each thread raises g to its
+// chunk start, then walks.
+__global__ void coset_table_kernel(Fr* tab, Fr g, Fr scale, uint32_t count, uint32_t chunk) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t start = (uint64_t)t * chunk;
+  if (start >= count) return;
+  Fr cur = mul(scale, pow_u64(g, start));
+  const uint32_t end = (uint32_t)((start + chunk < count) ? start + chunk : count);
+  for (uint32_t i = (uint32_t)start; i < end; i++) {
+    st_fr(tab + i, fr29_const_to_r261(cur));
+    cur = mul(cur, g);
+  }
+}
+
+// out[j][m] = sum_c w[j][c] * d[c][m], j < nout, c < nc (nc <= 8): the pieces of h(X) from its per-coset
+// interpolants. w: radix-2^261 constants, row-major [j][c].
+struct CombineW {
+  Fr w[64];
+};
+__global__ __launch_bounds__(256) void coset_combine_kernel(const Fr* d, Fr* out, uint32_t n, uint32_t nc, uint32_t nout, CombineW cw) {
+  const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n) return;
+  Fr v[8];
+  for (uint32_t c = 0; c < nc; c++) v[c] = ld_fr(d + (size_t)c * n + m);
+  for (uint32_t j = 0; j < nout; j++) {
+    Fr acc = fr29_mul_const(v[0], cw.w[j * nc]);
+    for (uint32_t c = 1; c < nc; c++) acc = add(acc, fr29_mul_const(v[c], cw.w[j * nc + c]));
+    st_fr(out + (size_t)j * n + m, acc);
+  }
 }
 
 }  // namespace
@@ -150,6 +190,8 @@ void amdzk_domain_free(amdzk_ctx* ctx, amdzk_domain* d) {
   if (!d) return;
   if (ctx) hipStreamSynchronize(ctx->stream);
   if (d->d_t_evaluations) hipFree(d->d_t_evaluations);
+  if (d->d_coset_in) hipFree(d->d_coset_in);
+  if (d->d_coset_out) hipFree(d->d_coset_out);
   delete d;
 }
 
@@ -170,13 +212,13 @@ int amdzk_lagrange_to_coeff_dev(amdzk_ctx* ctx, const amdzk_domain* d, void* d_c
   ZK_ENTER(ctx);
   if (!ctx || !d || !d_cols) return AMDZK_E_INVALID;
   Fr oc[3] = {d->ifft_divisor, d->ifft_divisor, d->ifft_divisor};
-  return zk_ntt_ex(ctx, (Fr*)d_cols, col_stride, (Fr*)d_cols, col_stride, d->k, (const uint64_t*)d->omega_inv.l, ncols, 0, nullptr, oc, nullptr);
+  return zk_ntt_ex(ctx, (Fr*)d_cols, col_stride, (Fr*)d_cols, col_stride, d->k, (const uint64_t*)d->omega_inv.l, ncols, 0, nullptr, oc, nullptr, nullptr);
 }
 
 int amdzk_coeff_to_lagrange_dev(amdzk_ctx* ctx, const amdzk_domain* d, void* d_cols, size_t ncols, size_t col_stride) {
   ZK_ENTER(ctx);
   if (!ctx || !d || !d_cols) return AMDZK_E_INVALID;
-  return zk_ntt_ex(ctx, (Fr*)d_cols, col_stride, (Fr*)d_cols, col_stride, d->k, (const uint64_t*)d->omega.l, ncols, 0, nullptr, nullptr, nullptr);
+  return zk_ntt_ex(ctx, (Fr*)d_cols, col_stride, (Fr*)d_cols, col_stride, d->k, (const uint64_t*)d->omega.l, ncols, 0, nullptr, nullptr, nullptr, nullptr);
 }
 
 int amdzk_coeff_to_extended_dev(amdzk_ctx* ctx, const amdzk_domain* d, const void* d_coeff, size_t in_stride,
@@ -185,32 +227,113 @@ int amdzk_coeff_to_extended_dev(amdzk_ctx* ctx, const amdzk_domain* d, const voi
   if (!ctx || !d || !d_coeff || !d_ext) return AMDZK_E_INVALID;
   Fr ic[2] = {d->g_coset, d->g_coset_inv};
   return zk_ntt_ex(ctx, (const Fr*)d_coeff, in_stride, (Fr*)d_ext, out_stride, d->extended_k,
-                   (const uint64_t*)d->extended_omega.l, ncols, 1u << d->k, ic, nullptr, nullptr);
+                   (const uint64_t*)d->extended_omega.l, ncols, 1u << d->k, ic, nullptr, nullptr, nullptr);
 }
 
-// The prover's private flavour of the two conversions. The h(X) interpreter multiplies data by data with
-// fp29.cuh's in-place product, which is closed only on radix-2^261 Montgomery values; x*2^261 is the same
-// 32 bytes as (32 x)*2^256, so "extended-domain data in radix 2^261" is simply 32 times the polynomial in
-// the ordinary form — a factor the (linear) transform picks up from its input constants for free, and
-// drops again through its output constants on the way back. The public amdzk_* entry points above are
-// unchanged.
-static Fr fr_k32() {
-  Fr k = Fr::one();
-  for (int i = 0; i < 5; i++) k = add(k, k);
-  return k;
+// ---- the quotient on nc cosets instead of the whole extended domain (prover-private).
+// h(X) = numerator / (X^n - 1) has degree below (j-1) n, so its j-1 pieces h_t (h = sum_t X^(t n) h_t) are pinned
+// down by the numerator on ANY j-1 cosets g_c H on which X^n - 1 does not vanish — upstream evaluates on all
+// 2^(ek-k) >= j-1 of them only because its domain is a power of two. On g_c H: X^n = g_c^n =: gamma_c is a
+// constant, so E_c(X) := h(X) on that coset is interpolated by h_0 + gamma_c h_1 + ... (degree below n): per coset
+// one size-n inverse transform, then one nc x nc inverse Vandermonde per coefficient. Same polynomial, hence the
+// same pieces and commitments, for 3/4 (degree 4) of the extended transforms and of the h(X) evaluation.
+// nc = 2^(ek-k) reproduces upstream's own computation exactly, also for witnesses that do not satisfy the circuit.
+int zk_quotient_plan(amdzk_ctx* ctx, amdzk_domain* d, uint32_t nc) {
+  const uint32_t ncosets = 1u << (d->extended_k - d->k);
+  if (nc == 0 || nc > ncosets) ZK_FAIL(ctx, AMDZK_E_INVALID, "quotient plan: %u cosets requested, the extended domain has %u", nc, ncosets);
+  if (nc > 8) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "quotient plan: more than 8 cosets (constraint degree above 9)");
+  if (d->nc == nc) return AMDZK_OK;
+  const size_t n = (size_t)1 << d->k;
+  if (d->d_coset_in) ZK_HIP(ctx, hipFree(d->d_coset_in));
+  if (d->d_coset_out) ZK_HIP(ctx, hipFree(d->d_coset_out));
+  d->d_coset_in = d->d_coset_out = nullptr;
+  d->nc = 0;
+  ZK_HIP(ctx, hipMalloc((void**)&d->d_coset_in, (size_t)nc * n * sizeof(Fr)));
+  ZK_HIP(ctx, hipMalloc((void**)&d->d_coset_out, (size_t)nc * n * sizeof(Fr)));
+  Fr k32 = Fr::one();
+  for (int i = 0; i < 5; i++) k32 = add(k32, k32);
+  const Fr base = inv(mul(k32, pow_u64(add(Fr::one(), Fr::one()), d->k)));  // 1 / (32 n)
+  d->coset_g.assign(nc, Fr::zero());
+  std::vector<Fr> gamma(nc);
+  const uint32_t chunk = 64;
+  dim3 grid((unsigned)(((n + chunk - 1) / chunk + 63) / 64)), block(64);
+  for (uint32_t c = 0; c < nc; c++) {
+    const Fr g = mul(d->g_coset, pow_u64(d->extended_omega, c));
+    d->coset_g[c] = g;
+    gamma[c] = pow_u64(g, n);
+    const Fr den = sub(gamma[c], Fr::one());
+    if (den.is_zero()) ZK_FAIL(ctx, AMDZK_E_INVALID, "quotient plan: X^n - 1 vanishes on coset %u", c);
+    ZK_LAUNCH(ctx, "coset_table", coset_table_kernel, grid, block, 0, d->d_coset_in + (size_t)c * n, g, k32, (uint32_t)n, chunk);
+    ZK_LAUNCH(ctx, "coset_table", coset_table_kernel, grid, block, 0, d->d_coset_out + (size_t)c * n, inv(g), mul(base, inv(den)), (uint32_t)n, chunk);
+  }
+  // vinv = V^-1 with V[c][t] = gamma_c^t (Gauss-Jordan on the host; nc <= 8)
+  std::vector<Fr> a((size_t)nc * 2 * nc, Fr::zero());
+  for (uint32_t c = 0; c < nc; c++) {
+    Fr p = Fr::one();
+    for (uint32_t t = 0; t < nc; t++) {
+      a[(size_t)c * 2 * nc + t] = p;
+      p = mul(p, gamma[c]);
+    }
+    a[(size_t)c * 2 * nc + nc + c] = Fr::one();
+  }
+  for (uint32_t col = 0; col < nc; col++) {
+    uint32_t piv = col;
+    while (piv < nc && a[(size_t)piv * 2 * nc + col].is_zero()) piv++;
+    if (piv == nc) ZK_FAIL(ctx, AMDZK_E_INVALID, "quotient plan: singular Vandermonde");
+    if (piv != col)
+      for (uint32_t t = 0; t < 2 * nc; t++) std::swap(a[(size_t)piv * 2 * nc + t], a[(size_t)col * 2 * nc + t]);
+    const Fr pi = inv(a[(size_t)col * 2 * nc + col]);
+    for (uint32_t t = 0; t < 2 * nc; t++) a[(size_t)col * 2 * nc + t] = mul(a[(size_t)col * 2 * nc + t], pi);
+    for (uint32_t r = 0; r < nc; r++) {
+      if (r == col) continue;
+      const Fr f = a[(size_t)r * 2 * nc + col];
+      if (f.is_zero()) continue;
+      for (uint32_t t = 0; t < 2 * nc; t++) a[(size_t)r * 2 * nc + t] = sub(a[(size_t)r * 2 * nc + t], mul(f, a[(size_t)col * 2 * nc + t]));
+    }
+  }
+  d->vinv.assign((size_t)nc * nc, Fr::zero());
+  for (uint32_t t = 0; t < nc; t++)
+    for (uint32_t c = 0; c < nc; c++) d->vinv[(size_t)t * nc + c] = a[(size_t)t * 2 * nc + nc + c];
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  d->nc = nc;
+  return AMDZK_OK;
 }
-int zk_coeff_to_extended_r261(amdzk_ctx* ctx, const amdzk_domain* d, const Fr* d_coeff, size_t in_stride, Fr* d_ext, size_t out_stride,
-                              size_t ncols) {
-  const Fr k32 = fr_k32();
-  Fr ic[2] = {mul(d->g_coset, k32), mul(d->g_coset_inv, k32)};
-  return zk_ntt_ex(ctx, d_coeff, in_stride, d_ext, out_stride, d->extended_k, (const uint64_t*)d->extended_omega.l, ncols, 1u << d->k, ic,
-                   nullptr, &k32);
+uint32_t zk_quotient_cosets(const amdzk_domain* d) { return d->nc; }
+Fr zk_quotient_coset_g(const amdzk_domain* d, uint32_t c) { return d->coset_g[c]; }
+
+// n coefficients per column -> nc x n evaluations, coset c of column y at d_out + y*out_stride + c*n, values in
+// radix 2^261 (what the h(X) program multiplies in): nc size-n transforms of a_m * (32 g_c^m).
+int zk_coeff_to_cosets_r261(amdzk_ctx* ctx, const amdzk_domain* d, const Fr* d_coeff, size_t in_stride, Fr* d_out, size_t out_stride,
+                            size_t ncols) {
+  if (!d->nc) ZK_FAIL(ctx, AMDZK_E_INVALID, "coeff_to_cosets: no quotient plan");
+  const size_t n = (size_t)1 << d->k;
+  if (out_stride < (size_t)d->nc * n) ZK_FAIL(ctx, AMDZK_E_INVALID, "coeff_to_cosets: output stride too small");
+  NttTables t;
+  t.in_tab = d->d_coset_in;
+  t.tab_z_stride = n;
+  t.nz = d->nc;
+  t.out_z_stride = n;
+  return zk_ntt_ex(ctx, d_coeff, in_stride, d_out, out_stride, d->k, (const uint64_t*)d->omega.l, ncols, 0, nullptr, nullptr, nullptr, &t);
 }
-int zk_extended_to_coeff_from_r261(amdzk_ctx* ctx, const amdzk_domain* d, Fr* d_ext, size_t ncols, size_t col_stride) {
-  const Fr div = mul(d->extended_ifft_divisor, inv(fr_k32()));
-  Fr oc[3] = {div, mul(div, d->g_coset_inv), mul(div, d->g_coset)};
-  return zk_ntt_ex(ctx, d_ext, col_stride, d_ext, col_stride, d->extended_k, (const uint64_t*)d->extended_omega_inv.l, ncols, 0, nullptr, oc,
-                   nullptr);
+
+// d_h: the h(X) numerator on the nc cosets ([nc][n], radix 2^261; overwritten) -> d_pieces: `npieces` <= nc pieces of
+// n coefficients each in the ordinary form (the division by X^n - 1 rides in the output table).
+int zk_cosets_to_pieces(amdzk_ctx* ctx, const amdzk_domain* d, Fr* d_h, Fr* d_pieces, uint32_t npieces) {
+  if (!d->nc) ZK_FAIL(ctx, AMDZK_E_INVALID, "cosets_to_pieces: no quotient plan");
+  if (npieces > d->nc) ZK_FAIL(ctx, AMDZK_E_INVALID, "cosets_to_pieces: %u pieces from %u cosets", npieces, d->nc);
+  const size_t n = (size_t)1 << d->k;
+  NttTables t;
+  t.out_tab = d->d_coset_out;
+  t.tab_col_stride = n;
+  ZK_TRY(zk_ntt_ex(ctx, d_h, n, d_h, n, d->k, (const uint64_t*)d->omega_inv.l, d->nc, 0, nullptr, nullptr, nullptr, &t));
+  CombineW cw;
+  for (uint32_t j = 0; j < npieces; j++)
+    for (uint32_t c = 0; c < d->nc; c++) {
+      cw.w[j * d->nc + c] = fr29_const_to_r261(d->vinv[(size_t)j * d->nc + c]);
+    }
+  ZK_LAUNCH(ctx, "coset_combine", coset_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (const Fr*)d_h, d_pieces, (uint32_t)n,
+            d->nc, npieces, cw);
+  return AMDZK_OK;
 }
 
 int amdzk_extended_to_coeff_dev(amdzk_ctx* ctx, const amdzk_domain* d, void* d_ext, size_t ncols, size_t col_stride) {
@@ -219,7 +342,7 @@ int amdzk_extended_to_coeff_dev(amdzk_ctx* ctx, const amdzk_domain* d, void* d_e
   // ifft divisor and the inverse coset powers [1, zeta^-1 = zeta^2, zeta^-2 = zeta] in one multiplier
   Fr oc[3] = {d->extended_ifft_divisor, mul(d->extended_ifft_divisor, d->g_coset_inv), mul(d->extended_ifft_divisor, d->g_coset)};
   return zk_ntt_ex(ctx, (Fr*)d_ext, col_stride, (Fr*)d_ext, col_stride, d->extended_k,
-                   (const uint64_t*)d->extended_omega_inv.l, ncols, 0, nullptr, oc, nullptr);
+                   (const uint64_t*)d->extended_omega_inv.l, ncols, 0, nullptr, oc, nullptr, nullptr);
 }
 
 int amdzk_divide_by_vanishing_dev(amdzk_ctx* ctx, const amdzk_domain* d, void* d_ext, size_t ncols, size_t col_stride) {

@@ -45,10 +45,13 @@ int amdzk_coeff_to_extended_dev(amdzk_ctx* ctx, const amdzk_domain* d, const voi
                                 size_t ncols);
 int amdzk_extended_to_coeff_dev(amdzk_ctx* ctx, const amdzk_domain* d, void* d_ext, size_t ncols, size_t col_stride);
 int amdzk_divide_by_vanishing_dev(amdzk_ctx* ctx, const amdzk_domain* d, void* d_ext, size_t ncols, size_t col_stride);
-// prover-private: extended-domain data in Montgomery radix 2^261 (poly.hip) — what the h(X) program multiplies in
-int zk_coeff_to_extended_r261(amdzk_ctx* ctx, const amdzk_domain* d, const Fr* d_coeff, size_t in_stride, Fr* d_ext, size_t out_stride,
-                              size_t ncols);
-int zk_extended_to_coeff_from_r261(amdzk_ctx* ctx, const amdzk_domain* d, Fr* d_ext, size_t ncols, size_t col_stride);
+// prover-private: the quotient domain = nc cosets of the size-n subgroup, data in Montgomery radix 2^261 (poly.hip) —
+// what the h(X) program multiplies in
+int zk_quotient_plan(amdzk_ctx* ctx, amdzk_domain* d, uint32_t nc);
+Fr zk_quotient_coset_g(const amdzk_domain* d, uint32_t c);
+int zk_coeff_to_cosets_r261(amdzk_ctx* ctx, const amdzk_domain* d, const Fr* d_coeff, size_t in_stride, Fr* d_out, size_t out_stride,
+                            size_t ncols);
+int zk_cosets_to_pieces(amdzk_ctx* ctx, const amdzk_domain* d, Fr* d_h, Fr* d_pieces, uint32_t npieces);
 int amdzk_fr_to_repr_dev(amdzk_ctx* ctx, void* d_a, size_t n);
 int amdzk_fr_from_raw_dev(amdzk_ctx* ctx, void* d_a, size_t n);
 }
@@ -124,7 +127,8 @@ struct RandomSource {
 
 struct amdzk_pk {
   uint32_t k = 0, ek = 0, bf = 0, degree = 0, F = 0, A = 0, I = 0, S = 0, L = 0, nsets = 0, chunk = 0, qdeg = 0;
-  size_t n = 0, ext = 0;
+  uint32_t nc = 0;       // cosets of the quotient domain (poly.hip zk_quotient_plan): qdeg of the 2^(ek-k) upstream uses
+  size_t n = 0, ext = 0;  // ext = nc * n rows: every "extended" column holds [coset][row]
   std::vector<std::pair<int, int>> advice_queries, fixed_queries, instance_queries;
   std::vector<std::pair<int, int>> perm_cols;  // (kind, index)
   std::vector<std::vector<uint32_t>> exprs;
@@ -145,7 +149,7 @@ struct amdzk_pk {
   size_t NP = 0;
   Fr *P = nullptr, *PC = nullptr;   // [NP][n], [NP][ext]
   Fr *ci = nullptr, *ct = nullptr;  // [L][n] compressed lookup input / table
-  Fr *rnd = nullptr, *hq = nullptr, *hpoly = nullptr, *frac = nullptr, *scratch = nullptr, *scan_tmp = nullptr;
+  Fr *rnd = nullptr, *hq = nullptr, *hpieces = nullptr, *hpoly = nullptr, *frac = nullptr, *scratch = nullptr, *scan_tmp = nullptr;
   Fr *sets_L = nullptr, *sets_N = nullptr, *hx = nullptr;  // SHPLONK buffers
   Fr *lk_ts = nullptr, *lk_left = nullptr;  // lookup permutation: sorted tables, leftovers [L][n]
   uint32_t* lk_flags = nullptr;              // [4][L][n+8]
@@ -424,7 +428,6 @@ int upload_consts261(amdzk_ctx* ctx, amdzk_pk* pk) {
 // and upload the 16-byte instructions.
 int upload_program(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, bool extended) {
   const std::vector<const Fr*>& cols = extended ? pk->h_cols_ext : pk->h_cols_lag;
-  const int32_t scale = extended ? (1 << (pk->ek - pk->k)) : 1;
   std::vector<ExprInstr> ins(pr.words.size());
   for (size_t i = 0; i < pr.words.size(); i++) {
     const uint32_t w = pr.words[i], op = w >> 24, arg = w & 0xffffffu;
@@ -434,7 +437,7 @@ int upload_program(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, bool extended) {
     if (op == OP_PUSH_COL || op == OP_MUL_COL || op == OP_ADD_COL || op == OP_SUB_COL) {
       if ((arg >> 8) >= cols.size() || (arg & 0xff) >= pk->rots.rots.size()) ZK_FAIL(ctx, AMDZK_E_INVALID, "program: bad column operand");
       ins[i].ptr = cols[arg >> 8];
-      ins[i].rot = pk->rots.rots[arg & 0xff] * scale;
+      ins[i].rot = pk->rots.rots[arg & 0xff];  // rows of one coset are consecutive: a rotation is a row offset in both domains
     } else if (op == OP_PUSH_CONST || op == OP_MUL_CONST || op == OP_ADD_CONST) {
       if (arg >= pk->consts.size()) ZK_FAIL(ctx, AMDZK_E_INVALID, "program: bad constant operand");
       ins[i].ptr = (extended ? pk->d_consts261 : pk->d_consts) + arg;
@@ -454,10 +457,10 @@ int run_program(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, bool extended, Fr* co
   a.outs = d_outs;
   a.h_out = h_out;
   a.nrows = extended ? pk->ext : pk->n;
-  a.mask = a.nrows - 1;
-  // Extended-domain programs (h(X), l_active) run in radix 2^261: their columns come from
-  // zk_coeff_to_extended_r261, their constants from d_consts261, and the result goes back through
-  // zk_extended_to_coeff_from_r261. Lagrange-domain programs read the caller's radix-2^256 witness as is.
+  a.mask = pk->n - 1;
+  // Quotient-domain programs (h(X), l_active) run in radix 2^261: their columns come from
+  // zk_coeff_to_cosets_r261, their constants from d_consts261, and the result goes back through
+  // zk_cosets_to_pieces. Lagrange-domain programs read the caller's radix-2^256 witness as is.
   a.radix261 = extended ? 1u : 0u;
   a.y_ptr = (extended ? pk->d_consts261 : pk->d_consts) + pk->c_y;
   for (int i = 0; i < EXPR_HOT; i++) a.hot[i] = EXPR_NO_SLOT;
@@ -572,12 +575,13 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
   memcpy(pk->transcript_repr.l, transcript_repr, 32);
   KG_TRY(amdzk_domain_new(ctx, pk->degree, pk->k, &pk->dom));
   pk->ek = amdzk_domain_extended_k(pk->dom);
-  pk->ext = (size_t)1 << pk->ek;
+  // h(X) has qdeg = degree - 1 pieces: that many cosets pin it down (AMDZK_FULL_COSETS=1: all 2^(ek-k), upstream's own
+  // computation — identical output for satisfying witnesses, and the way to reproduce upstream's bytes for others)
+  pk->nc = getenv("AMDZK_FULL_COSETS") ? (1u << (pk->ek - pk->k)) : pk->qdeg;
+  KG_TRY(zk_quotient_plan(ctx, pk->dom, pk->nc));
+  pk->ext = (size_t)pk->nc * pk->n;
   amdzk_domain_constant(pk->dom, 0, (uint64_t*)pk->omega.l);
   amdzk_domain_constant(pk->dom, 1, (uint64_t*)pk->omega_inv.l);
-  Fr ext_omega, zeta;
-  amdzk_domain_constant(pk->dom, 2, (uint64_t*)ext_omega.l);
-  amdzk_domain_constant(pk->dom, 4, (uint64_t*)zeta.l);
   for (uint32_t i = 0; i < c->num_advice_queries; i++) pk->advice_queries.push_back({c->advice_queries[2 * i], c->advice_queries[2 * i + 1]});
   for (uint32_t i = 0; i < c->num_fixed_queries; i++) pk->fixed_queries.push_back({c->fixed_queries[2 * i], c->fixed_queries[2 * i + 1]});
   for (uint32_t i = 0; i < c->num_instance_queries; i++)
@@ -632,6 +636,7 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
   KG_TRY(dalloc(ctx, pk, &pk->d_err, 1));
   KG_TRY(dalloc(ctx, pk, &pk->rnd, n));
   KG_TRY(dalloc(ctx, pk, &pk->hq, ext));
+  KG_TRY(dalloc(ctx, pk, &pk->hpieces, (size_t)pk->qdeg * n));
   KG_TRY(dalloc(ctx, pk, &pk->hpoly, n));
   const size_t nfrac = std::max<size_t>(std::max<size_t>(ns, L), 1);
   KG_TRY(dalloc(ctx, pk, &pk->frac, nfrac * n));
@@ -674,15 +679,17 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
     for (int t = 0; t < 3; t++) {
       KG_TRY(h2d(ctx, tmp, src[t]->data(), n * 32));
       KG_TRY(amdzk_lagrange_to_coeff_dev(ctx, pk->dom, tmp, 1, n));
-      KG_TRY(zk_coeff_to_extended_r261(ctx, pk->dom, tmp, n, dst[t], ext, 1));
+      KG_TRY(zk_coeff_to_cosets_r261(ctx, pk->dom, tmp, n, dst[t], ext, 1));
       ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     std::vector<Fr> xc(ext);
-    cur = zeta;
-    for (int i = 0; i < 5; i++) cur = add(cur, cur);  // 32 * zeta * omega_ext^i: the coset points in radix 2^261
-    for (size_t i = 0; i < ext; i++) {
-      xc[i] = cur;
-      cur = mul(cur, ext_omega);
+    for (uint32_t c = 0; c < pk->nc; c++) {
+      cur = zk_quotient_coset_g(pk->dom, c);
+      for (int i = 0; i < 5; i++) cur = add(cur, cur);  // 32 * g_c * omega^i: the points of coset c in radix 2^261
+      for (size_t i = 0; i < n; i++) {
+        xc[(size_t)c * n + i] = cur;
+        cur = mul(cur, pk->omega);
+      }
     }
     KG_TRY(h2d(ctx, pk->x_coset, xc.data(), ext * 32));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -696,7 +703,7 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
     KG_TRY(h2d(ctx, pk->fixed_lag, fixed_values, (size_t)F * n * 32));
     KG_TRY(d2d(ctx, pk->fixed_poly, pk->fixed_lag, (size_t)F * n * 32));
     KG_TRY(amdzk_lagrange_to_coeff_dev(ctx, pk->dom, pk->fixed_poly, F, n));
-    KG_TRY(zk_coeff_to_extended_r261(ctx, pk->dom, pk->fixed_poly, n, pk->fixed_coset, ext, F));
+    KG_TRY(zk_coeff_to_cosets_r261(ctx, pk->dom, pk->fixed_poly, n, pk->fixed_coset, ext, F));
     KG_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G_LAGRANGE, pk->fixed_lag, F, pk->fixed_commitments));
   }
   if (S) {
@@ -729,7 +736,7 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     KG_TRY(d2d(ctx, pk->sigma_poly, pk->sigma_lag, (size_t)S * n * 32));
     KG_TRY(amdzk_lagrange_to_coeff_dev(ctx, pk->dom, pk->sigma_poly, S, n));
-    KG_TRY(zk_coeff_to_extended_r261(ctx, pk->dom, pk->sigma_poly, n, pk->sigma_coset, ext, S));
+    KG_TRY(zk_coeff_to_cosets_r261(ctx, pk->dom, pk->sigma_poly, n, pk->sigma_coset, ext, S));
     KG_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G_LAGRANGE, pk->sigma_lag, S, pk->perm_commitments));
   }
   // l_active = 1 - (l_last + l_blind) on the coset: lactive_c currently holds l_blind's coset
@@ -1297,16 +1304,17 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
   ZK_TRY(h2d_staged(ctx, pk, pk->d_consts + pk->c_y, &pk->consts[pk->c_y], 32));
   // 6. every committed column: Lagrange -> coefficients -> extended coset; then h(X)
   ZK_TRY(amdzk_lagrange_to_coeff_dev(ctx, pk->dom, pk->P, pk->NP, n));
-  ZK_TRY(zk_coeff_to_extended_r261(ctx, pk->dom, pk->P, n, pk->PC, ext, pk->NP));
+  ZK_TRY(zk_coeff_to_cosets_r261(ctx, pk->dom, pk->P, n, pk->PC, ext, pk->NP));
   ZK_TRY(upload_consts261(ctx, pk));  // theta, beta, gamma, delta powers, y are all known by now
   tick("intt+coset_ntt");
+  // the numerator on the nc cosets, then division by X^n - 1, per-coset interpolation and the inverse Vandermonde
+  // in one go: the pieces of h(X) (upstream: divide_by_vanishing_poly + extended_to_coeff + chunks of n)
   ZK_TRY(run_program(ctx, pk, pk->prog_h, true, nullptr, pk->hq, "expr_evaluate_h"));
-  ZK_TRY(amdzk_divide_by_vanishing_dev(ctx, pk->dom, pk->hq, 1, ext));
-  ZK_TRY(zk_extended_to_coeff_from_r261(ctx, pk->dom, pk->hq, 1, ext));
+  ZK_TRY(zk_cosets_to_pieces(ctx, pk->dom, pk->hq, pk->hpieces, pk->qdeg));
   {
     for (uint32_t i = 0; i < pk->qdeg; i++) (void)rng.fr();  // h_blinds
     std::vector<G1Affine> cm;
-    ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G, pk->hq, pk->qdeg, cm));  // pieces are consecutive n-blocks of hq
+    ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G, pk->hpieces, pk->qdeg, cm));  // consecutive n-blocks
     ZK_TRY(write_points(cm, "h_piece"));
   }
   tick("h_eval+commit");
@@ -1319,7 +1327,7 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     std::vector<Fr> cf(pk->qdeg);
     Fr cur = Fr::one();
     for (uint32_t i = 0; i < pk->qdeg; i++) {
-      pp[i] = pk->hq + (size_t)i * n;
+      pp[i] = pk->hpieces + (size_t)i * n;
       cf[i] = cur;
       cur = mul(cur, xn);
     }

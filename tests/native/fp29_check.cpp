@@ -41,6 +41,20 @@ int main() {
     if (!eq(fq29_to_r256(f29_sub3(a, b)), sub(x, y))) { fails++; printf("sub3\n"); }
     if (!eq(fq29_to_r256(f29_sub10(a, f29_add(f29_add(b, b), b))), sub(x, add(add(y, y), y)))) { fails++; printf("sub10\n"); }
     if (!eq(fq29_pack_canonical(fq29_unpack(x)), x)) { fails++; printf("pack\n"); }
+    // dedicated squaring and the two-products-one-reduction form, on canonical and on lazily reduced operands
+    if (!eq(fq29_to_r256(f29_sqr(a)), sqr(x))) { fails++; printf("sqr\n"); }
+    {
+      Fq z = rand_fq(), w = rand_fq();
+      Fq29 c = fq29_from_r256(z), d = fq29_from_r256(w);
+      if (!eq(fq29_to_r256(f29_mul2(a, b, c, d)), add(mul(x, y), mul(z, w)))) { fails++; printf("mul2\n"); }
+      if (!eq(fq29_to_r256(f29_mul2(a, b, f29_neg3(c), d)), sub(mul(x, y), mul(z, w)))) { fails++; printf("mul2 with neg3\n"); }
+      // the shapes the point formulas use: r < 8p, t < 12p, (6p - y) with y < 5p, ppp < 2p
+      Fq29 r8 = f29_sub6(a, f29_add(f29_add(b, b), f29_add(b, b))), t12 = f29_sub10(c, f29_add(f29_add(d, d), f29_add(d, d)));
+      Fq29 y5 = f29_add(f29_add(c, c), f29_add(c, d));
+      Fq r8v = sub(x, add(add(y, y), add(y, y))), t12v = sub(z, add(add(w, w), add(w, w))), y5v = add(add(z, z), add(z, w));
+      if (!eq(fq29_to_r256(f29_mul2(r8, t12, f29_neg6(y5), b)), sub(mul(r8v, t12v), mul(y5v, y)))) { fails++; printf("mul2 lazy\n"); }
+      if (!eq(fq29_to_r256(f29_sqr(t12)), sqr(t12v))) { fails++; printf("sqr lazy\n"); }
+    }
     if (fails > 5) return 1;
   }
   printf("Fq29 field ok\n");
