@@ -375,6 +375,25 @@ int amdzk_ptr_check_affinity(amdzk_ctx* ctx, const void* dptr) {
 }
 int amdzk_ctx_device(const amdzk_ctx* ctx) { return ctx ? ctx->device : -1; }
 
+// best_fft on ncols host vectors of 2^log_n in one submission (one transfer each way per column).
+int amdzk_ntt_fr_batch(amdzk_ctx* ctx, uint64_t* const* cols, size_t ncols, uint32_t log_n, const uint64_t omega[4], uint32_t flags) {
+  ZK_ENTER(ctx);
+  if (!ctx) return AMDZK_E_INVALID;
+  if (!cols || !omega || ncols == 0) ZK_FAIL(ctx, AMDZK_E_INVALID, "ntt_batch: null pointer or ncols == 0");
+  if (log_n > 27) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "ntt: log_n %u > 27", log_n);
+  const size_t n = (size_t)1 << log_n;
+  Fr* d = nullptr;
+  ZK_TRY(zk_ws_reserve(ctx, 2, ncols * n * sizeof(Fr), (void**)&d));
+  for (size_t c = 0; c < ncols; c++) {
+    if (!cols[c]) ZK_FAIL(ctx, AMDZK_E_INVALID, "ntt_batch: column %zu is null", c);
+    ZK_HIP(ctx, hipMemcpyAsync(d + c * n, cols[c], n * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+  }
+  ZK_TRY(zk_ntt_dev(ctx, d, log_n, omega, flags, ncols, n));
+  for (size_t c = 0; c < ncols; c++) ZK_HIP(ctx, hipMemcpyAsync(cols[c], d + c * n, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AMDZK_OK;
+}
+
 int amdzk_timer_start(amdzk_ctx* ctx) {
   ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;

@@ -187,35 +187,35 @@ constexpr int SCAN_BLOCK = 256 * SCAN_E;
 
 __global__ __launch_bounds__(256) void scan_local_kernel(const Fr* in, Fr* out, Fr* totals, size_t n, size_t col_stride,
                                                          uint32_t nblk) {
-  // NOTE: this kernel deliberately keeps bn254.cuh's 32-bit product. With fp29.cuh's fr29_mul_std inlined here (and only
-  // here) hipcc 7.2 -O3 produces wrong running products, while the same function called out of line, and every other
-  // kernel with it inlined, is bit-exact (bisected on MI355X with the byte-equality tests; the product itself matches
-  // mul() on 3.3e6 device-side and 2e5 host-side full-range cases, tools/dev_check_mul_std.hip). The kernel is ~0.6 %
-  // of the prover's instructions, so nothing is lost by leaving it alone.
+  // No per-thread array here: the element values are read again from global memory in the second pass (in == out is
+  // allowed: a thread reads each of its own elements before it overwrites it). Round 1 kept them in `Fr m[SCAN_E]`,
+  // which hipcc placed in scratch memory (the loops are not fully unrolled, so the index is dynamic); with the 29-bit
+  // product inlined, the dead carry-out of its v_mad_u64_u32 was allocated to the very SGPR the scratch addresses
+  // were formed in, and the build returned wrong running products (tools/repro_valu_salu_sgpr_waw.hip).
   __shared__ Fr part[256];
   const uint32_t col = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
   const Fr* src = in + (size_t)col * col_stride;
   Fr* dst = out + (size_t)col * col_stride;
   const size_t base = (size_t)blk * SCAN_BLOCK + (size_t)t * SCAN_E;
-  Fr m[SCAN_E];
-#pragma unroll
-  for (int i = 0; i < SCAN_E; i++) m[i] = base + i < n ? ld_fr(src + base + i) : Fr::one();
-  Fr tot = m[0];
-#pragma unroll
-  for (int i = 1; i < SCAN_E; i++) tot = mul(tot, m[i]);
+  Fr tot = Fr::one();
+#pragma unroll 1
+  for (int i = 0; i < SCAN_E; i++)
+    if (base + i < n) tot = i == 0 ? ld_fr(src + base) : fr29_mul_std(tot, ld_fr(src + base + i));
   part[t] = tot;
   __syncthreads();
   for (uint32_t d = 1; d < 256; d <<= 1) {  // Hillis-Steele inclusive product scan
     Fr v = t >= d ? part[t - d] : Fr::one();
     __syncthreads();
-    if (t >= d) part[t] = mul(v, part[t]);
+    if (t >= d) part[t] = fr29_mul_std(v, part[t]);
     __syncthreads();
   }
   Fr pre = t == 0 ? Fr::one() : part[t - 1];
-#pragma unroll
+#pragma unroll 1
   for (int i = 0; i < SCAN_E; i++) {
-    if (base + i < n) st_fr(dst + base + i, pre);
-    pre = mul(pre, m[i]);
+    if (base + i >= n) break;
+    const Fr v = ld_fr(src + base + i);
+    st_fr(dst + base + i, pre);
+    pre = fr29_mul_std(pre, v);
   }
   if (t == 255) st_fr(totals + (size_t)col * nblk + blk, part[255]);
 }
@@ -669,3 +669,89 @@ int zk_lookup_permute(amdzk_ctx* ctx, Fr* A, Fr* Ts, Fr* S, Fr* left, size_t L, 
   ZK_LAUNCH(ctx, "lookup_assign", lookup_assign_kernel, grid, block, 0, A, left, S, (size_t)n, u, rep, rank_rep, rank_left, flag_stride, d_err);
   return AMDZK_OK;
 }
+
+// ------------------------------------------------------------------------------ C ABI, function by function
+// The kernels above under the names SURVEY.md §8(b) lists, on device-resident columns (Montgomery Fr, halo2curves'
+// in-memory form). Small operands (points, coefficients, roots, pointer lists) come from the host.
+namespace {
+int upload_ptrs_and_frs(amdzk_ctx* ctx, const void* const* ptrs, size_t nptrs, const uint64_t* frs, size_t nfrs, size_t extra_frs, void*** d_ptrs,
+                        Fr** d_frs) {
+  char* ws = nullptr;
+  const size_t pbytes = (nptrs * sizeof(void*) + 255) / 256 * 256;
+  ZK_TRY(zk_ws_reserve(ctx, 6, pbytes + (nfrs + extra_frs) * sizeof(Fr) + 256, (void**)&ws));
+  if (nptrs) ZK_HIP(ctx, hipMemcpyAsync(ws, ptrs, nptrs * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+  if (nfrs) ZK_HIP(ctx, hipMemcpyAsync(ws + pbytes, frs, nfrs * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the host arrays belong to the caller
+  *d_ptrs = (void**)ws;
+  *d_frs = (Fr*)(ws + pbytes);
+  return AMDZK_OK;
+}
+}  // namespace
+
+extern "C" {
+
+// ff::BatchInvert over n elements in place: every non-zero element is replaced by its inverse, zeros stay zero.
+int amdzk_batch_invert_dev(amdzk_ctx* ctx, void* d_a, size_t n) {
+  ZK_ENTER(ctx);
+  if (!ctx) return AMDZK_E_INVALID;
+  if (!d_a && n) ZK_FAIL(ctx, AMDZK_E_INVALID, "batch_invert: null pointer");
+  Fr* scratch = nullptr;
+  ZK_TRY(zk_ws_reserve(ctx, 7, (n ? n : 1) * sizeof(Fr), (void**)&scratch));
+  return zk_batch_invert(ctx, (Fr*)d_a, scratch, n);
+}
+
+// The running product of permutation::prover::Argument::commit / lookup::prover::commit_product: column c of
+// d_cols (n elements at + c * col_stride) is replaced by z with z[0] = 1, z[i] = z[i-1] * f[i-1]. chain != 0 threads the
+// permutation argument's last_z through the columns: z_c[0] = z_{c-1}[chain_row] instead of 1.
+int amdzk_grand_product_dev(amdzk_ctx* ctx, void* d_cols, size_t ncols, size_t n, size_t col_stride, int chain, size_t chain_row) {
+  ZK_ENTER(ctx);
+  if (!ctx) return AMDZK_E_INVALID;
+  if (!d_cols && ncols) ZK_FAIL(ctx, AMDZK_E_INVALID, "grand_product: null pointer");
+  if (ncols > 65535 || col_stride < n || (chain && chain_row >= n)) ZK_FAIL(ctx, AMDZK_E_INVALID, "grand_product: bad shape");
+  Fr* tmp = nullptr;
+  ZK_TRY(zk_ws_reserve(ctx, 7, (zk_scan_totals_elems(n, ncols) + 2 * ncols + 8) * sizeof(Fr), (void**)&tmp));
+  return zk_running_product(ctx, (Fr*)d_cols, ncols, n, col_stride, chain != 0, chain_row, tmp);
+}
+
+// arithmetic::eval_polynomial for nq (polynomial, point) pairs: out[q] = d_polys[q](points[q]); polynomials are n
+// coefficients on the device (d_polys: host array of device pointers), points and results on the host.
+int amdzk_eval_poly_dev(amdzk_ctx* ctx, const void* const* d_polys, const uint64_t* points, size_t nq, uint32_t n, uint64_t* out) {
+  ZK_ENTER(ctx);
+  if (!ctx) return AMDZK_E_INVALID;
+  if (nq == 0) return AMDZK_OK;
+  if (!d_polys || !points || !out) ZK_FAIL(ctx, AMDZK_E_INVALID, "eval_poly: null pointer");
+  void** dp = nullptr;
+  Fr* df = nullptr;
+  ZK_TRY(upload_ptrs_and_frs(ctx, d_polys, nq, points, nq, nq, &dp, &df));
+  ZK_TRY(zk_poly_eval(ctx, (const Fr* const*)dp, df, df + nq, nq, n));
+  ZK_HIP(ctx, hipMemcpyAsync(out, df + nq, nq * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AMDZK_OK;
+}
+
+// d_out[i] = (accumulate ? d_out[i] : 0) + sum_j coefs[j] * d_polys[j][i], i < n: the linear combinations of
+// multiopen (sum_j y^j P_j, the h(X) fold by x^n, ...). d_out must not alias an input.
+int amdzk_poly_axpy_dev(amdzk_ctx* ctx, const void* const* d_polys, const uint64_t* coefs, size_t m, void* d_out, size_t n, int accumulate) {
+  ZK_ENTER(ctx);
+  if (!ctx) return AMDZK_E_INVALID;
+  if ((m && (!d_polys || !coefs)) || (!d_out && n)) ZK_FAIL(ctx, AMDZK_E_INVALID, "poly_axpy: null pointer");
+  void** dp = nullptr;
+  Fr* df = nullptr;
+  ZK_TRY(upload_ptrs_and_frs(ctx, d_polys, m, coefs, m, 0, &dp, &df));
+  return zk_lincomb(ctx, (const Fr* const*)dp, df, (uint32_t)m, (Fr*)d_out, n, accumulate != 0);
+}
+
+// arithmetic::kate_division in place for npolys polynomials of n coefficients: a(X) -> (a(X) - a(root)) / (X - root),
+// n coefficients with the top one zero (upstream returns n - 1).
+int amdzk_kate_div_dev(amdzk_ctx* ctx, void* const* d_polys, const uint64_t* roots, size_t npolys, uint32_t n) {
+  ZK_ENTER(ctx);
+  if (!ctx) return AMDZK_E_INVALID;
+  if (npolys == 0) return AMDZK_OK;
+  if (!d_polys || !roots) ZK_FAIL(ctx, AMDZK_E_INVALID, "kate_div: null pointer");
+  void** dp = nullptr;
+  Fr* df = nullptr;
+  ZK_TRY(upload_ptrs_and_frs(ctx, (const void* const*)d_polys, npolys, roots, npolys, 0, &dp, &df));
+  return zk_kate_div(ctx, (Fr* const*)dp, df, npolys, n);
+}
+
+}  // extern "C"

@@ -246,6 +246,31 @@ int d2d(amdzk_ctx* ctx, void* dst, const void* src, size_t bytes) {
   return AMDZK_OK;
 }
 
+// lookup::prover::permute_expression_pair for L lookups at once, on Montgomery-form columns of n rows each:
+// A (compressed inputs, [L][n]) is sorted in place into A', S ([L][n]) receives the aligned table S'; rows >= usable
+// of both come back zero (the caller blinds them). T: the compressed tables (read only). Ts / left: [L][n] scratch,
+// flags: 4 x L x (n + 8) u32 scratch. Canonical keys (numeric order = upstream's Ord for Fr), rows >= usable padded
+// with an all-ones sentinel (> any canonical value) so the power-of-two sort leaves the real rows in front.
+int zk_permute_expression_pairs(amdzk_ctx* ctx, Fr* A, const Fr* T, Fr* Ts, Fr* S, Fr* left, uint32_t* flags, int* d_err, size_t L, uint32_t n,
+                                uint32_t usable) {
+  if (L == 0) return AMDZK_OK;
+  ZK_TRY(d2d(ctx, Ts, T, L * n * 32));
+  ZK_TRY(amdzk_fr_to_repr_dev(ctx, A, L * n));
+  ZK_TRY(amdzk_fr_to_repr_dev(ctx, Ts, L * n));
+  ZK_HIP(ctx, hipMemset2DAsync(A + usable, (size_t)n * 32, 0xFF, (size_t)(n - usable) * 32, L, ctx->stream));
+  ZK_HIP(ctx, hipMemset2DAsync(Ts + usable, (size_t)n * 32, 0xFF, (size_t)(n - usable) * 32, L, ctx->stream));
+  ZK_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(int), ctx->stream));
+  ZK_TRY(zk_lookup_permute(ctx, A, Ts, S, left, L, n, usable, flags, (size_t)n + 8, d_err));
+  ZK_HIP(ctx, hipMemset2DAsync(A + usable, (size_t)n * 32, 0, (size_t)(n - usable) * 32, L, ctx->stream));
+  ZK_HIP(ctx, hipMemset2DAsync(S + usable, (size_t)n * 32, 0, (size_t)(n - usable) * 32, L, ctx->stream));
+  ZK_TRY(amdzk_fr_from_raw_dev(ctx, A, L * n));
+  ZK_TRY(amdzk_fr_from_raw_dev(ctx, S, L * n));
+  int herr = 0;
+  ZK_TRY(d2h(ctx, &herr, d_err, sizeof(int)));
+  if (herr) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: lookup %d input not in table (ConstraintSystemFailure)", herr - 1);
+  return AMDZK_OK;
+}
+
 // MSM of ncols resident columns -> affine points on the host
 int commit_cols(amdzk_ctx* ctx, amdzk_pk* pk, int basis, const Fr* d_cols, size_t ncols, std::vector<G1Affine>& out) {
   out.resize(ncols);
@@ -519,6 +544,18 @@ void trace_pt(const char* label, const G1Affine& p) {
 }
 
 }  // namespace
+
+// plonk::evaluation::Evaluator::evaluate_h + divide_by_vanishing_poly + extended_to_coeff + the split into pieces
+// (SURVEY.md §8(a) rows a6, a7, a10): from the committed polynomials in coefficient form (pk->P, arena order) and the
+// challenges in pk->consts to the degree-1 pieces of h(X) in pk->hpieces. The numerator is evaluated on nc cosets of
+// the size-n subgroup (poly.hip, zk_quotient_plan), then divided by X^n - 1, interpolated per coset and recombined.
+static int quotient_pieces(amdzk_ctx* ctx, amdzk_pk* pk) {
+  ZK_TRY(zk_coeff_to_cosets_r261(ctx, pk->dom, pk->P, pk->n, pk->PC, pk->ext, pk->NP));
+  ZK_TRY(upload_consts261(ctx, pk));
+  ZK_TRY(run_program(ctx, pk, pk->prog_h, true, nullptr, pk->hq, "expr_evaluate_h"));
+  ZK_TRY(zk_cosets_to_pieces(ctx, pk->dom, pk->hq, pk->hpieces, pk->qdeg));
+  return AMDZK_OK;
+}
 
 extern "C" {
 
@@ -1122,7 +1159,7 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
   ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
   if (!pk || !proof_len || (pk->A && !d_advice)) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: null argument");
-  const size_t n = pk->n, ext = pk->ext;
+  const size_t n = pk->n;
   const uint32_t F = pk->F, A = pk->A, I = pk->I, S = pk->S, L = pk->L, ns = pk->nsets, bf = pk->bf;
   const size_t usable = n - (bf + 1);
   if (advice_stride < n) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: advice stride < n");
@@ -1192,27 +1229,12 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
   trace_fr("theta", theta);
   pk->consts[pk->c_theta] = theta;
   ZK_TRY(h2d_staged(ctx, pk, pk->d_consts + pk->c_theta, &pk->consts[pk->c_theta], 32));
-  // 2. lookups: compress, permute (host, round 1), blind, commit
+  // 2. lookups: compress, permute (on the device), blind, commit
   if (L) {
     ZK_TRY(run_program(ctx, pk, pk->prog_compress, false, pk->d_outs_compress, nullptr, "expr_lookup_compress"));
-    // permute_expression_pair on the device: canonical keys, rows >= usable padded with an all-ones
-    // sentinel (> any canonical value) so the power-of-two sort leaves the real rows in front.
     ZK_TRY(d2d(ctx, pk->la(), pk->ci, (size_t)L * n * 32));
-    ZK_TRY(d2d(ctx, pk->lk_ts, pk->ct, (size_t)L * n * 32));
-    ZK_TRY(amdzk_fr_to_repr_dev(ctx, pk->la(), (size_t)L * n));
-    ZK_TRY(amdzk_fr_to_repr_dev(ctx, pk->lk_ts, (size_t)L * n));
-    ZK_HIP(ctx, hipMemset2DAsync(pk->la() + usable, n * 32, 0xFF, (n - usable) * 32, L, ctx->stream));
-    ZK_HIP(ctx, hipMemset2DAsync(pk->lk_ts + usable, n * 32, 0xFF, (n - usable) * 32, L, ctx->stream));
-    ZK_HIP(ctx, hipMemsetAsync(pk->d_err, 0, sizeof(int), ctx->stream));
-    ZK_TRY(zk_lookup_permute(ctx, pk->la(), pk->lk_ts, pk->ls(), pk->lk_left, L, (uint32_t)n, (uint32_t)usable, pk->lk_flags, n + 8, pk->d_err));
-    ZK_HIP(ctx, hipMemset2DAsync(pk->la() + usable, n * 32, 0, (n - usable) * 32, L, ctx->stream));
-    ZK_HIP(ctx, hipMemset2DAsync(pk->ls() + usable, n * 32, 0, (n - usable) * 32, L, ctx->stream));
-    ZK_TRY(amdzk_fr_from_raw_dev(ctx, pk->la(), (size_t)2 * L * n));
-    {
-      int herr = 0;
-      ZK_TRY(d2h(ctx, &herr, pk->d_err, sizeof(int)));
-      if (herr) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: lookup %d input not in table (ConstraintSystemFailure)", herr - 1);
-    }
+    ZK_TRY(zk_permute_expression_pairs(ctx, pk->la(), pk->ct, pk->lk_ts, pk->ls(), pk->lk_left, pk->lk_flags, pk->d_err, L, (uint32_t)n,
+                                       (uint32_t)usable));
     tick("  lookup: device permute");
     // RNG order per lookup: a' tail, s' tail, blind(a'), blind(s')
     std::vector<Fr> ta((size_t)L * (bf + 1)), ts((size_t)L * (bf + 1));
@@ -1304,13 +1326,7 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
   ZK_TRY(h2d_staged(ctx, pk, pk->d_consts + pk->c_y, &pk->consts[pk->c_y], 32));
   // 6. every committed column: Lagrange -> coefficients -> extended coset; then h(X)
   ZK_TRY(amdzk_lagrange_to_coeff_dev(ctx, pk->dom, pk->P, pk->NP, n));
-  ZK_TRY(zk_coeff_to_cosets_r261(ctx, pk->dom, pk->P, n, pk->PC, ext, pk->NP));
-  ZK_TRY(upload_consts261(ctx, pk));  // theta, beta, gamma, delta powers, y are all known by now
-  tick("intt+coset_ntt");
-  // the numerator on the nc cosets, then division by X^n - 1, per-coset interpolation and the inverse Vandermonde
-  // in one go: the pieces of h(X) (upstream: divide_by_vanishing_poly + extended_to_coeff + chunks of n)
-  ZK_TRY(run_program(ctx, pk, pk->prog_h, true, nullptr, pk->hq, "expr_evaluate_h"));
-  ZK_TRY(zk_cosets_to_pieces(ctx, pk->dom, pk->hq, pk->hpieces, pk->qdeg));
+  ZK_TRY(quotient_pieces(ctx, pk));  // theta, beta, gamma, delta powers, y are all known by now
   {
     for (uint32_t i = 0; i < pk->qdeg; i++) (void)rng.fr();  // h_blinds
     std::vector<G1Affine> cm;
@@ -1642,6 +1658,85 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
   }
   (void)F;
   return AMDZK_OK;
+}
+
+// ---- function-by-function entry points of the PLONK layer: the same kernels create_proof runs,
+// callable on their own — by the isolated parity tests and by a fork that replaces upstream one function at a time.
+
+// evaluate_h and the quotient: d_polys = the NP = A + I + 2L + nsets + L committed polynomials in COEFFICIENT form, n
+// each, in the key's arena order [advice | instance | permuted inputs A' | permuted tables S' | permutation products
+// | lookup products]; the challenges as Montgomery Fr. Writes the cs_degree - 1 pieces of h(X) (n coefficients each)
+// to d_pieces_out. Uses (and overwrites) the key's per-proof workspace.
+int amdzk_quotient_eval_dev(amdzk_ctx* ctx, amdzk_pk* pk, const void* d_polys, size_t poly_stride, const uint64_t theta[4],
+                            const uint64_t beta[4], const uint64_t gamma[4], const uint64_t y[4], void* d_pieces_out) {
+  ZK_ENTER(ctx);
+  if (!ctx) return AMDZK_E_INVALID;
+  if (!pk || !d_polys || !theta || !beta || !gamma || !y || !d_pieces_out) ZK_FAIL(ctx, AMDZK_E_INVALID, "quotient_eval: null argument");
+  if (poly_stride < pk->n) ZK_FAIL(ctx, AMDZK_E_INVALID, "quotient_eval: stride < n");
+  ZK_HIP(ctx, hipMemcpy2DAsync(pk->P, pk->n * 32, d_polys, poly_stride * 32, pk->n * 32, pk->NP, hipMemcpyDeviceToDevice, ctx->stream));
+  memcpy(pk->consts[pk->c_theta].l, theta, 32);
+  memcpy(pk->consts[pk->c_beta].l, beta, 32);
+  memcpy(pk->consts[pk->c_gamma].l, gamma, 32);
+  memcpy(pk->consts[pk->c_y].l, y, 32);
+  Fr cur = pk->consts[pk->c_beta], delta = fr_delta();
+  for (uint32_t j = 0; j < pk->S; j++) {
+    pk->consts[pk->c_bdelta + j] = cur;
+    cur = mul(cur, delta);
+  }
+  ZK_TRY(quotient_pieces(ctx, pk));
+  ZK_TRY(d2d(ctx, d_pieces_out, pk->hpieces, (size_t)pk->qdeg * pk->n * 32));
+  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AMDZK_OK;
+}
+
+// What the last create_proof on this key left in its workspace, for tests that check one stage at a time against the
+// oracle: what = 0 the NP committed polynomials in coefficient form ([NP][n], arena order as above); 1 the
+// challenges theta, beta, gamma, y; 2 the pieces of h(X) ([cs_degree - 1][n]). `out` holds cap Fr elements;
+// *count = elements available.
+int amdzk_pk_inspect(amdzk_ctx* ctx, const amdzk_pk* pk, int what, uint64_t* out, size_t cap, size_t* count) {
+  ZK_ENTER(ctx);
+  if (!ctx) return AMDZK_E_INVALID;
+  if (!pk || !count) ZK_FAIL(ctx, AMDZK_E_INVALID, "pk_inspect: null argument");
+  const Fr* src = nullptr;
+  size_t cnt = 0;
+  Fr ch[4];
+  if (what == 0) {
+    src = pk->P;
+    cnt = pk->NP * pk->n;
+  } else if (what == 2) {
+    src = pk->hpieces;
+    cnt = (size_t)pk->qdeg * pk->n;
+  } else if (what == 1) {
+    ch[0] = pk->consts[pk->c_theta];
+    ch[1] = pk->consts[pk->c_beta];
+    ch[2] = pk->consts[pk->c_gamma];
+    ch[3] = pk->consts[pk->c_y];
+    cnt = 4;
+  } else {
+    ZK_FAIL(ctx, AMDZK_E_INVALID, "pk_inspect: unknown selector %d", what);
+  }
+  *count = cnt;
+  if (!out) return AMDZK_OK;
+  if (cap < cnt) ZK_FAIL(ctx, AMDZK_E_INVALID, "pk_inspect: buffer holds %zu elements, %zu needed", cap, cnt);
+  if (what == 1) memcpy(out, ch, sizeof(ch));
+  else ZK_TRY(d2h(ctx, out, src, cnt * 32));
+  return AMDZK_OK;
+}
+
+// lookup::prover::permute_expression_pair for nlookups (input, table) pairs of n rows each, Montgomery form,
+// column l at + l * n: d_inputs is sorted in place into A', d_permuted_tables_out receives S'; rows >= usable of both
+// are zero. Fails with "not in table" when an input value is missing from its table.
+int amdzk_permute_expression_pair_dev(amdzk_ctx* ctx, void* d_inputs, const void* d_tables, void* d_permuted_tables_out, size_t nlookups,
+                                      uint32_t n, uint32_t usable) {
+  ZK_ENTER(ctx);
+  if (!ctx) return AMDZK_E_INVALID;
+  if (!d_inputs || !d_tables || !d_permuted_tables_out) ZK_FAIL(ctx, AMDZK_E_INVALID, "permute_expression_pair: null argument");
+  if (n < 2 || (n & (n - 1)) || usable > n) ZK_FAIL(ctx, AMDZK_E_INVALID, "permute_expression_pair: n must be a power of two >= usable");
+  char* ws = nullptr;  // Ts[L][n] | left[L][n] | flags 4 x L x (n + 8) | err
+  const size_t L = nlookups, col = L * (size_t)n * 32, fl = 4 * L * ((size_t)n + 8) * 4;
+  ZK_TRY(zk_ws_reserve(ctx, 5, 2 * col + fl + 256, (void**)&ws));
+  return zk_permute_expression_pairs(ctx, (Fr*)d_inputs, (const Fr*)d_tables, (Fr*)ws, (Fr*)d_permuted_tables_out, (Fr*)(ws + col),
+                                     (uint32_t*)(ws + 2 * col), (int*)(ws + 2 * col + fl), L, n, usable);
 }
 
 }  // extern "C"

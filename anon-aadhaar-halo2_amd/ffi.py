@@ -82,6 +82,15 @@ def lib():
         "amdzk_proof_random_count": (sz, [vp]),
         "amdzk_proof_size": (sz, [vp, i32]),
         "amdzk_create_proof_scalars": (i32, [vp, vp, C.POINTER(vp), C.POINTER(sz), vp, sz, vp, sz, i32, vp, sz, C.POINTER(sz)]),
+        "amdzk_ntt_fr_batch": (i32, [vp, C.POINTER(vp), sz, u32, vp, u32]),
+        "amdzk_batch_invert_dev": (i32, [vp, vp, sz]),
+        "amdzk_grand_product_dev": (i32, [vp, vp, sz, sz, sz, i32, sz]),
+        "amdzk_eval_poly_dev": (i32, [vp, C.POINTER(vp), vp, sz, u32, vp]),
+        "amdzk_poly_axpy_dev": (i32, [vp, C.POINTER(vp), vp, sz, vp, sz, i32]),
+        "amdzk_kate_div_dev": (i32, [vp, C.POINTER(vp), vp, sz, u32]),
+        "amdzk_permute_expression_pair_dev": (i32, [vp, vp, vp, vp, sz, u32, u32]),
+        "amdzk_quotient_eval_dev": (i32, [vp, vp, vp, sz, vp, vp, vp, vp, vp]),
+        "amdzk_pk_inspect": (i32, [vp, vp, i32, vp, sz, C.POINTER(sz)]),
         "amdzk_timer_start": (i32, [vp]),
         "amdzk_timer_stop": (i32, [vp, C.POINTER(C.c_float)]),
         "amdzk_prof_enable": (i32, [vp, i32]),

@@ -63,3 +63,85 @@ def g_to_lagrange(ctx, g, k):
     out = np.zeros_like(g)
     ctx._chk(ctx.L.amdzk_g_to_lagrange(ctx.h, _ptr(g), k, _ptr(out)))
     return out
+
+
+# ---- the PLONK layer's helpers, function by function (include/amdzk.h "function by function"); host arrays in,
+# host arrays out: each call uploads, runs the device kernel create_proof itself uses, and downloads.
+def _dev_cols(ctx, cols):
+    cols = [as_fr_array(c) for c in cols]
+    n = cols[0].shape[0]
+    assert all(c.shape[0] == n for c in cols)
+    buf = ctx.alloc(max(1, len(cols) * n * 32))
+    buf.upload(np.ascontiguousarray(np.stack(cols)) if n else np.zeros((0, 4), np.uint64))
+    return buf, n
+
+
+def batch_invert(ctx, a):
+    """ff::BatchInvert: inverses of the non-zero elements, zeros stay zero."""
+    a = as_fr_array(a)
+    buf = ctx.alloc(max(1, a.nbytes)).upload(a)
+    ctx._chk(ctx.L.amdzk_batch_invert_dev(ctx.h, buf.ptr, a.shape[0]))
+    out = buf.download(a.shape)
+    buf.free()
+    return out
+
+
+def grand_product(ctx, cols, chain=False, chain_row=0):
+    """Running products z[0] = 1, z[i] = z[i-1] * f[i-1] of every column (permutation / lookup commit_product);
+    chain: z_c[0] = z_{c-1}[chain_row]."""
+    buf, n = _dev_cols(ctx, cols)
+    ctx._chk(ctx.L.amdzk_grand_product_dev(ctx.h, buf.ptr, len(cols), n, n, 1 if chain else 0, chain_row))
+    out = buf.download((len(cols), n, 4))
+    buf.free()
+    return out
+
+
+def eval_polynomial(ctx, polys, points):
+    """arithmetic::eval_polynomial(poly, point) for a list of (poly, point) pairs."""
+    buf, n = _dev_cols(ctx, polys)
+    pts = as_fr_array(points)
+    assert pts.shape[0] == len(polys)
+    ptrs = (C.c_void_p * len(polys))(*[buf.ptr.value + i * n * 32 for i in range(len(polys))])
+    out = np.zeros((len(polys), 4), np.uint64)
+    ctx._chk(ctx.L.amdzk_eval_poly_dev(ctx.h, ptrs, _ptr(pts), len(polys), n, _ptr(out)))
+    buf.free()
+    return out
+
+
+def poly_axpy(ctx, polys, coefs):
+    """sum_j coefs[j] * polys[j]."""
+    buf, n = _dev_cols(ctx, polys)
+    cf = as_fr_array(coefs)
+    ptrs = (C.c_void_p * len(polys))(*[buf.ptr.value + i * n * 32 for i in range(len(polys))])
+    out = ctx.alloc(max(1, n * 32))
+    ctx._chk(ctx.L.amdzk_poly_axpy_dev(ctx.h, ptrs, _ptr(cf), len(polys), out.ptr, n, 0))
+    res = out.download((n, 4))
+    buf.free()
+    out.free()
+    return res
+
+
+def kate_division(ctx, polys, roots):
+    """arithmetic::kate_division(a, root) for each pair: (a(X) - a(root)) / (X - root), n - 1 coefficients."""
+    buf, n = _dev_cols(ctx, polys)
+    rt = as_fr_array(roots)
+    ptrs = (C.c_void_p * len(polys))(*[buf.ptr.value + i * n * 32 for i in range(len(polys))])
+    ctx._chk(ctx.L.amdzk_kate_div_dev(ctx.h, ptrs, _ptr(rt), len(polys), n))
+    out = buf.download((len(polys), n, 4))
+    buf.free()
+    assert not out[:, n - 1].any(), "kate_division: top coefficient must be zero"
+    return out[:, : n - 1]
+
+
+def permute_expression_pair(ctx, inputs, tables, usable):
+    """lookup::prover::permute_expression_pair for a list of (input, table) column pairs of n rows: returns
+    (A', S') as (L, n, 4) arrays, rows >= usable zero (the caller blinds them)."""
+    a_buf, n = _dev_cols(ctx, inputs)
+    t_buf, n2 = _dev_cols(ctx, tables)
+    assert n == n2 and len(inputs) == len(tables)
+    s_buf = ctx.alloc(len(inputs) * n * 32)
+    try:
+        ctx._chk(ctx.L.amdzk_permute_expression_pair_dev(ctx.h, a_buf.ptr, t_buf.ptr, s_buf.ptr, len(inputs), n, usable))
+        return a_buf.download((len(inputs), n, 4)), s_buf.download((len(inputs), n, 4))
+    finally:
+        a_buf.free(); t_buf.free(); s_buf.free()

@@ -347,6 +347,33 @@ class ProvingKey:
         self.ctx._chk(self.ctx.L.amdzk_pk_commitments(self.h, f.ctypes.data if f.size else None, p.ctypes.data if p.size else None))
         return f, p
 
+    def inspect(self, what):
+        """Test hook (amdzk_pk_inspect): what the last create_proof left in the key's workspace. 0: the committed
+        polynomials in coefficient form (NP, n, 4), arena order advice | instance | A' | S' | Z_perm | Z_lookup;
+        1: the challenges theta, beta, gamma, y (4, 4); 2: the pieces of h(X) (cs_degree - 1, n, 4)."""
+        cnt = C.c_size_t(0)
+        self.ctx._chk(self.ctx.L.amdzk_pk_inspect(self.ctx.h, self.h, what, None, 0, C.byref(cnt)))
+        out = np.zeros((cnt.value, 4), np.uint64)
+        self.ctx._chk(self.ctx.L.amdzk_pk_inspect(self.ctx.h, self.h, what, out.ctypes.data, cnt.value, C.byref(cnt)))
+        n = 1 << self.desc["k"]
+        return out if what == 1 else out.reshape(-1, n, 4)
+
+    def quotient_eval(self, polys, theta, beta, gamma, y):
+        """evaluate_h + the quotient (amdzk_quotient_eval_dev): committed polynomials in coefficient form (NP, n, 4)
+        and the challenges -> the pieces of h(X) (cs_degree - 1, n, 4)."""
+        n = 1 << self.desc["k"]
+        polys = np.ascontiguousarray(polys, dtype=np.uint64).reshape(-1, n, 4)
+        d_in = self.ctx.alloc(polys.nbytes).upload(polys)
+        qdeg = self.desc["cs_degree"] - 1
+        d_out = self.ctx.alloc(qdeg * n * 32)
+        ch = [np.ascontiguousarray(c, dtype=np.uint64).reshape(4) for c in (theta, beta, gamma, y)]
+        try:
+            self.ctx._chk(self.ctx.L.amdzk_quotient_eval_dev(self.ctx.h, self.h, d_in.ptr, n, ch[0].ctypes.data, ch[1].ctypes.data,
+                                                             ch[2].ctypes.data, ch[3].ctypes.data, d_out.ptr))
+            return d_out.download((qdeg, n, 4))
+        finally:
+            d_in.free(); d_out.free()
+
     def free(self):
         if self.h:
             self.ctx.L.amdzk_pk_free(self.ctx.h, self.h)

@@ -146,6 +146,10 @@ int amdzk_ntt_fr(amdzk_ctx* ctx, uint64_t* a, uint32_t log_n, const uint64_t ome
 int amdzk_ntt_fr_dev(amdzk_ctx* ctx, void* d_a, uint32_t log_n, const uint64_t omega[4],
                      uint32_t flags, size_t ncols, size_t col_stride);
 
+/* ncols host vectors of 2^log_n in one submission. */
+int amdzk_ntt_fr_batch(amdzk_ctx* ctx, uint64_t* const* cols, size_t ncols, uint32_t log_n,
+                       const uint64_t omega[4], uint32_t flags);
+
 /* ---- representation changes on resident data: Fr::from_raw (canonical 4 x u64 -> Montgomery) and
  * Fr::to_repr (Montgomery -> canonical), n elements in place. Values must be < r. */
 int amdzk_fr_from_raw_dev(amdzk_ctx* ctx, void* d_a, size_t n);
@@ -250,6 +254,45 @@ int amdzk_create_proof_scalars(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* con
                                size_t advice_stride, const uint64_t* scalars, size_t scalar_count,
                                int transcript_kind, uint8_t* proof_out, size_t proof_cap,
                                size_t* proof_len);
+
+/* ---- the PLONK layer function by function: the kernels create_proof runs,
+ * callable on their own on device-resident columns — for a fork that replaces upstream one function at a time and
+ * for the isolated parity tests (tests/test_gpu_plonk_ops.py). Small operands come from the host. */
+/* ff::BatchInvert [UP] in place: non-zero elements are inverted, zeros stay zero. */
+int amdzk_batch_invert_dev(amdzk_ctx* ctx, void* d_a, size_t n);
+/* The running product of permutation::prover::Argument::commit and lookup::prover::commit_product [UP]: column c
+ * (n elements at d_cols + c*col_stride) is replaced by z with z[0] = 1, z[i] = z[i-1] * f[i-1]; with chain != 0 the
+ * permutation argument's last_z is threaded through the columns: z_c[0] = z_{c-1}[chain_row]. */
+int amdzk_grand_product_dev(amdzk_ctx* ctx, void* d_cols, size_t ncols, size_t n, size_t col_stride,
+                            int chain, size_t chain_row);
+/* arithmetic::eval_polynomial [UP] for nq (polynomial, point) pairs: out[q] = d_polys[q](points[q]). d_polys: host
+ * array of device pointers to n coefficients; points and out on the host. */
+int amdzk_eval_poly_dev(amdzk_ctx* ctx, const void* const* d_polys, const uint64_t* points, size_t nq,
+                        uint32_t n, uint64_t* out);
+/* d_out = (accumulate ? d_out : 0) + sum_j coefs[j] * d_polys[j] over n coefficients (multiopen's linear
+ * combinations). d_out must not alias an input. */
+int amdzk_poly_axpy_dev(amdzk_ctx* ctx, const void* const* d_polys, const uint64_t* coefs, size_t m,
+                        void* d_out, size_t n, int accumulate);
+/* arithmetic::kate_division [UP] in place: a(X) -> (a(X) - a(root)) / (X - root); n coefficients, the top one 0. */
+int amdzk_kate_div_dev(amdzk_ctx* ctx, void* const* d_polys, const uint64_t* roots, size_t npolys, uint32_t n);
+/* lookup::prover::permute_expression_pair [UP] for nlookups pairs of n rows (column l at + l*n, Montgomery form):
+ * d_inputs is sorted in place into A', d_permuted_tables_out receives S' (first occurrences aligned, leftovers in
+ * ascending order assigned from the last repeated row backwards); rows >= usable come back zero for the caller to
+ * blind. AMDZK_E_INVALID "not in table" when an input value is missing from its table. */
+int amdzk_permute_expression_pair_dev(amdzk_ctx* ctx, void* d_inputs, const void* d_tables,
+                                      void* d_permuted_tables_out, size_t nlookups, uint32_t n, uint32_t usable);
+/* evaluation::Evaluator::evaluate_h + divide_by_vanishing_poly + extended_to_coeff + the split into pieces [UP]:
+ * d_polys = the key's NP = A + I + 2L + nsets + L committed polynomials in coefficient form, n each, at
+ * d_polys + i*poly_stride, in the order advice | instance | A' | S' | permutation products | lookup products;
+ * challenges as Montgomery Fr. Writes the cs_degree - 1 pieces of h(X) (n coefficients each, consecutive) to
+ * d_pieces_out. Overwrites the key's per-proof workspace. */
+int amdzk_quotient_eval_dev(amdzk_ctx* ctx, amdzk_pk* pk, const void* d_polys, size_t poly_stride,
+                            const uint64_t theta[4], const uint64_t beta[4], const uint64_t gamma[4],
+                            const uint64_t y[4], void* d_pieces_out);
+/* What the last create_proof on this key left in its workspace (test hook): what = 0 the NP committed polynomials in
+ * coefficient form [NP][n]; 1 the challenges theta, beta, gamma, y; 2 the pieces of h(X) [cs_degree - 1][n].
+ * out may be NULL to query *count (in Fr elements). */
+int amdzk_pk_inspect(amdzk_ctx* ctx, const amdzk_pk* pk, int what, uint64_t* out, size_t cap, size_t* count);
 
 /* ---- timing / profiling hooks used by bench.py (HIP events on this ctx's stream) ------------ */
 int amdzk_timer_start(amdzk_ctx* ctx);
