@@ -29,11 +29,22 @@
                : [acc] "+v"(acc), [out] "=&v"(got)                                            \
                : [x] "v"(x), [y] "v"(y), [base] "s"(base + 64u)                               \
                : "s20", "s21", "s22", "s23", "scc", "memory")
+// Second pattern, also taken from that ISA: the load is issued FIRST and the v_mad that overwrites its address SGPR
+// with a carry-out comes right behind it (write-after-read), FILL instructions later.
+#define SEQ_WAR(SDST, FILL)                                                                   \
+  asm volatile("s_mov_b32 s20, %[base]\n\t"                                                   \
+               "s_nop 4\n\t"                                                                  \
+               "scratch_load_dword %[out], off, s20\n\t" FILL                                 \
+               "v_mad_u64_u32 %[acc], " SDST ", %[x], %[y], %[acc]\n\t"                       \
+               "s_waitcnt vmcnt(0)"                                                           \
+               : [acc] "+v"(acc), [out] "=&v"(got)                                            \
+               : [x] "v"(x), [y] "v"(y), [base] "s"(base + 64u)                               \
+               : "s20", "s21", "s22", "s23", "scc", "memory")
 #define F1 "v_xor_b32 %[x], %[x], %[y]\n\t"
 
 __device__ __forceinline__ bool base_unused_guard(volatile uint32_t* p) { return p[63] != 1063u; }
 
-template <int SAME>
+template <int SAME, int WAR>
 __global__ void probe(uint32_t* bad, uint32_t iters) {
   volatile uint32_t priv[64];
   for (int i = 0; i < 64; i++) priv[i] = 1000u + (uint32_t)i;
@@ -48,7 +59,8 @@ __global__ void probe(uint32_t* bad, uint32_t iters) {
   uint32_t wrong[7] = {0, 0, 0, 0, 0, 0, 0};
   for (uint32_t it = 0; it < iters; it++) {
 #define RUN(N, FILL)                                          \
-  if (SAME) SEQ("s[20:21]", FILL); else SEQ("s[22:23]", FILL); \
+  if (WAR) { if (SAME) SEQ_WAR("s[20:21]", FILL); else SEQ_WAR("s[22:23]", FILL); } \
+  else { if (SAME) SEQ("s[20:21]", FILL); else SEQ("s[22:23]", FILL); } \
   wrong[N] += got != 1016u;
     RUN(0, "")
     RUN(1, F1)
@@ -65,10 +77,15 @@ __global__ void probe(uint32_t* bad, uint32_t iters) {
 int main() {
   uint32_t* d;
   hipMalloc(&d, 8 * sizeof(uint32_t));
+  for (int war = 0; war < 2; war++)
   for (int same = 1; same >= 0; same--) {
     hipMemset(d, 0, 8 * sizeof(uint32_t));
-    if (same) hipLaunchKernelGGL(probe<1>, dim3(64), dim3(256), 0, 0, d, 100u);
-    else hipLaunchKernelGGL(probe<0>, dim3(64), dim3(256), 0, 0, d, 100u);
+    printf("%s ", war ? "load, then v_mad writes its address SGPR (WAR):" : "v_mad, s_mov, load (WAW):                       ");
+    if (war) {
+      if (same) hipLaunchKernelGGL((probe<1, 1>), dim3(64), dim3(256), 0, 0, d, 100u);
+      else hipLaunchKernelGGL((probe<0, 1>), dim3(64), dim3(256), 0, 0, d, 100u);
+    } else if (same) hipLaunchKernelGGL((probe<1, 0>), dim3(64), dim3(256), 0, 0, d, 100u);
+    else hipLaunchKernelGGL((probe<0, 0>), dim3(64), dim3(256), 0, 0, d, 100u);
     if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 2; }
     uint32_t h[8];
     hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);

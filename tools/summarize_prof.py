@@ -1,12 +1,22 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 output (gpurun_out/prof/{stats,fetch,write}) into profiles/<tag>_kernel_summary.csv.
-Usage: python tools/summarize_prof.py gpurun_out/prof r01"""
+"""Condense the rocprofv3 passes of tools/profile_gpu.sh (gpurun_out/prof/{stats,fetch,write,insts}/run_results.db —
+ROCm 7.2 writes rocpd SQLite databases) into tracked files:
+  profiles/<tag>_rocprofv3_kernel_stats.csv   rocprofv3 --kernel-trace --stats: calls, total / average ns, share
+  profiles/<tag>_kernel_summary.csv           the same plus FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU per launch (--pmc passes)
+  profiles/<tag>_valu_instruction_counts.txt  instruction totals per kernel and per proof
+The first line of the summary stamps the hash of the kernel sources the run was made with (bench.kernel_src_hash):
+bench.py uses a summary's counters only when that hash is its own build's.
+Usage: python tools/summarize_prof.py gpurun_out/prof r02d [proofs_in_run]"""
 import collections
-import csv
-import glob
 import os
 import re
+import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+STARTUP = ("table_next_kernel", "table_to_r261_kernel", "fixed_base_mul_kernel", "powers_kernel", "twiddle_gen_kernel",
+           "sub_from_const_kernel", "mul2_kernel", "coset_table_kernel")
 
 
 def short(name):
@@ -15,40 +25,74 @@ def short(name):
     return name.split("(")[0][:60]
 
 
+def db(src, kind):
+    p = os.path.join(src, kind, "run_results.db")
+    return sqlite3.connect(p) if os.path.exists(p) else None
+
+
 def main():
     src, tag = sys.argv[1], sys.argv[2]
+    proofs = float(sys.argv[3]) if len(sys.argv) > 3 else 3.0  # warm-up + timed + the profiled extra proof of bench.py
     os.makedirs("profiles", exist_ok=True)
-    stats = {}
-    f = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
-    if f:
-        for r in csv.DictReader(open(f[0])):
-            stats[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]) / 1e6, float(r["Percentage"]))
+    stats = collections.OrderedDict()
+    c = db(src, "stats")
+    if c:
+        rows = c.execute("select name, count(*), sum(duration), avg(duration) from kernels group by name order by sum(duration) desc").fetchall()
+        total = sum(r[2] for r in rows) or 1
+        with open(os.path.join("profiles", tag + "_rocprofv3_kernel_stats.csv"), "w") as o:
+            o.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage"\n')
+            for name, calls, tot, avg in rows:
+                o.write('"%s",%d,%d,%.1f,%.2f\n' % (name, calls, tot, avg, 100.0 * tot / total))
+                k = short(name)
+                if k.startswith("at::") or "rocclr" in k or "elementwise" in k:
+                    continue
+                stats[k] = (calls, avg / 1e6, 100.0 * tot / total)
     pmc = {}
-    for kind in ("fetch", "write"):
-        f = glob.glob(os.path.join(src, kind, "*", "*_counter_collection.csv"))
+    per_counter = collections.defaultdict(lambda: collections.defaultdict(float))
+    calls_insts = collections.Counter()
+    for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"), ("insts", "SQ_INSTS_VALU")):
         agg = collections.defaultdict(lambda: [0, 0.0])
-        if f:
-            for r in csv.DictReader(open(f[0])):
-                k = short(r["Kernel_Name"])
-                agg[k][0] += 1
-                agg[k][1] += float(r["Counter_Value"])
+        c = db(src, kind)
+        if c:
+            for name, cname, val in c.execute("select name, counter_name, sum(counter_value) from pmc_events group by dispatch_id, name, counter_name"):
+                k = short(name)
+                if kind == "insts":
+                    per_counter[k][cname] += val
+                    if cname == "SQ_WAVES":
+                        calls_insts[k] += 1
+                if cname == counter:
+                    agg[k][0] += 1
+                    agg[k][1] += float(val)
         pmc[kind] = agg
-    rows = []
-    for k, (calls, avg_ms, pct) in sorted(stats.items(), key=lambda kv: -kv[1][2]):
-        if k.startswith("at::") or "rocclr" in k:
-            continue
-        fe = pmc["fetch"].get(k)
-        wr = pmc["write"].get(k)
-        rows.append((k, calls, avg_ms, pct, fe[1] / fe[0] if fe else None, wr[1] / wr[0] if wr else None))
+    import bench
     path = os.path.join("profiles", tag + "_kernel_summary.csv")
     with open(path, "w") as o:
+        o.write("# kernel_src_sha256=%s\n" % bench.kernel_src_hash())
         o.write("kernel,calls,avg_ms,pct_of_gpu_time,FETCH_SIZE_KiB_per_launch_raw,WRITE_SIZE_KiB_per_launch_raw,"
-                "hbm_MB_per_launch_corrected(2*FETCH+WRITE)\n")
-        for k, calls, avg_ms, pct, fe, wr in rows:
+                "hbm_MB_per_launch_corrected(2*FETCH+WRITE),SQ_INSTS_VALU_per_launch\n")
+        for k, (calls, avg_ms, pct) in stats.items():
+            fe, wr, va = (pmc[x].get(k) for x in ("fetch", "write", "insts"))
+            fe = fe[1] / fe[0] if fe else None
+            wr = wr[1] / wr[0] if wr else None
+            va = va[1] / va[0] if va else None
             corr = "" if fe is None or wr is None else "%.2f" % ((2 * fe + wr) * 1024 / 1e6)
-            o.write("%s,%d,%.4f,%.2f,%s,%s,%s\n" % (k, calls, avg_ms, pct, "" if fe is None else "%.1f" % fe,
-                                                   "" if wr is None else "%.1f" % wr, corr))
+            o.write('"%s",%d,%.4f,%.2f,%s,%s,%s,%s\n' % (k, calls, avg_ms, pct, "" if fe is None else "%.1f" % fe, "" if wr is None else "%.1f" % wr,
+                                                     corr, "" if va is None else "%.0f" % va))
     print(open(path).read())
+    if per_counter:
+        per_proof = sum(v.get("SQ_INSTS_VALU", 0) for k, v in per_counter.items() if k not in STARTUP)
+        with open(os.path.join("profiles", tag + "_valu_instruction_counts.txt"), "w") as o:
+            o.write("rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES -- python3 bench.py --steps 1 --warmup 1 "
+                    "--concurrency 1 --no-cpu-baseline --no-stream-pass\n(shape full, k = 15, kernel sources %s; keygen + %.2f proofs)\n\n" % (bench.kernel_src_hash(), proofs))
+            o.write("%-46s %6s %12s %10s %10s %10s %10s\n" % ("kernel", "calls", "VALU", "SALU", "LDS", "VMEM_RD", "waves"))
+            for k, v in sorted(per_counter.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0))[:24]:
+                o.write("%-46s %6d %12.3e %10.2e %10.2e %10.2e %10.2e%s\n" % (k[:46], calls_insts[k], v.get("SQ_INSTS_VALU", 0), v.get("SQ_INSTS_SALU", 0),
+                                                                      v.get("SQ_INSTS_LDS", 0), v.get("SQ_INSTS_VMEM_RD", 0), v.get("SQ_WAVES", 0),
+                                                                      "   (start-up)" if k in STARTUP else ""))
+            o.write("\nVALU wave-instructions outside the start-up kernels: %.3e over %.2f proofs = %.3e per proof\n" % (per_proof, proofs, per_proof / proofs))
+            for cpi in (4.0, 4.5, 5.0):
+                o.write("  at %.1f cycles per VALU wave-instruction on 1024 SIMDs at 2.4 GHz: %.1f ms per proof\n" % (cpi, per_proof / proofs * cpi / (1024 * 2.4e9) * 1e3))
+        print(open(os.path.join("profiles", tag + "_valu_instruction_counts.txt")).read())
 
 
 if __name__ == "__main__":
