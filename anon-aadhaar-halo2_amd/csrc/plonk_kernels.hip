@@ -39,18 +39,18 @@ __device__ __forceinline__ void st_fr(Fr* p, const Fr& v) {
 }
 
 // ------------------------------------------------------------------------------ interpreter
-// Two latency measures, both value-neutral: (1) columns that almost every constraint touches at
-// rotation 0 (l_0, l_last, l_active and the coset point X) are loaded once per row into registers
-// ("hot" slots, ExprArgs::hot); (2) the column operand of the NEXT instruction is fetched while the
+// Two latency measures, both value-neutral: (1) in the quotient-domain interpreter the columns that almost every
+// constraint touches at rotation 0 (l_0, l_last, l_active and the coset point X) are loaded once per row into
+// registers ("hot" slots, ExprArgs::hot); (2) the column operand of the NEXT instruction is fetched while the
 // current one executes, so a global load is in flight behind every field multiplication.
 __device__ __forceinline__ bool op_reads_col(uint32_t op) {
   return op == OP_PUSH_COL || op == OP_MUL_COL || op == OP_ADD_COL || op == OP_SUB_COL;
 }
 
-template <bool R261>
+// Lagrange-domain programs (lookup compression, the fractions of the grand products): columns, constants and results in
+// halo2curves' radix-2^256 form, packed values on the stack. (Quotient-domain programs: expr_eval_limbs_kernel below.)
 __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_kernel(ExprArgs a) {
-  // the one place the two radices differ: the product (sums, differences, negation act on canonical values)
-  auto fmul = [](const Fr& x, const Fr& y) -> Fr { return R261 ? fr29_mul_rr(x, y) : fr29_mul_std(x, y); };
+  auto fmul = [](const Fr& x, const Fr& y) -> Fr { return fr29_mul_std(x, y); };
   extern __shared__ uint4 lds_raw[];
   Fr* stack = reinterpret_cast<Fr*>(lds_raw);  // [depth][EXPR_THREADS]
   const uint32_t tid = threadIdx.x;
@@ -59,9 +59,6 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_kernel(ExprArgs a) {
   Fr tos = Fr::zero();
   Fr h = Fr::zero();
   const Fr yv = a.y_ptr ? ld_fr(a.y_ptr) : Fr::zero();
-  Fr hot[EXPR_HOT];
-#pragma unroll
-  for (int i = 0; i < EXPR_HOT; i++) hot[i] = a.hot[i] != EXPR_NO_SLOT ? ld_fr(a.cols[a.hot[i]] + row) : Fr::zero();
   uint32_t sp = 0;  // elements on the stack, including tos
   // Software pipeline over the (wave-uniform) instruction stream: while instruction pc executes, the
   // operand of pc+1 is in flight (vector load) and instruction pc+2 is being fetched (scalar load).
@@ -95,14 +92,6 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_kernel(ExprArgs a) {
         break;
       case OP_SUB_COL:
         tos = sub(tos, v);
-        break;
-      case OP_PUSH_HOT:
-        if (sp > 0) stack[(sp - 1) * EXPR_THREADS + tid] = tos;
-        tos = arg == 0 ? hot[0] : arg == 1 ? hot[1] : arg == 2 ? hot[2] : hot[3];
-        sp++;
-        break;
-      case OP_MUL_HOT:
-        tos = fmul(tos, arg == 0 ? hot[0] : arg == 1 ? hot[1] : arg == 2 ? hot[2] : hot[3]);
         break;
       case OP_PUSH_CONST:
         if (sp > 0) stack[(sp - 1) * EXPR_THREADS + tid] = tos;
@@ -150,6 +139,167 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_kernel(ExprArgs a) {
     nxt = nn;
   }
   if (a.h_out) st_fr(a.h_out + row, h);
+}
+
+// ------------------------------------------------------------------------------ interpreter, limb-resident
+// The h(X) program (radix 2^261 data) spends most of its time in products whose operands and results used to be packed
+// to canonical 32-byte values and unpacked again around every operation (81 of 310 instructions per product). Here the
+// top of stack, the accumulator h, the hot columns and y live on 9 x 29-bit limbs (fp29.cuh), lazily reduced: sums
+// and differences are limb-wise with a carry pass, products reset the bound to 2p, and the host — which knows the
+// whole (wave-uniform) program — tracks every value's bound and inserts OP_REDUCE where a product or a difference
+// would leave its range (prover.hip finalize_limb_program). `h = h*y + tos*x`, the end of nearly every gate and
+// argument term, is one two-product reduction (f29_mul2). Columns and constants are unpacked when they are read;
+// the operand stack below the top is in LDS as limbs (36 B per entry). No per-thread arrays, so nothing in scratch.
+__device__ __forceinline__ Fr29 lds_ld29(const uint32_t* s, uint32_t slot, uint32_t tid) {
+  Fr29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = s[(slot * 9 + i) * EXPR_THREADS + tid];
+  return r;
+}
+__device__ __forceinline__ void lds_st29(uint32_t* s, uint32_t slot, uint32_t tid, const Fr29& v) {
+#pragma unroll
+  for (int i = 0; i < 9; i++) s[(slot * 9 + i) * EXPR_THREADS + tid] = v.l[i];
+}
+
+__global__ __launch_bounds__(EXPR_THREADS) void expr_eval_limbs_kernel(ExprArgs a) {
+  extern __shared__ uint4 lds_raw[];
+  uint32_t* stack = reinterpret_cast<uint32_t*>(lds_raw);  // [depth][9][EXPR_THREADS]
+  const uint32_t tid = threadIdx.x;
+  const size_t row = (size_t)blockIdx.x * EXPR_THREADS + tid;
+  if (row >= a.nrows) return;  // no barriers below
+  Fr29 tos, h;
+#pragma unroll
+  for (int i = 0; i < 9; i++) tos.l[i] = h.l[i] = 0;
+  // y and the hot columns as named values, selected limb by limb: an indexed array, or a `?:` between whole structs,
+  // makes hipcc keep them in scratch memory
+  Fr29 yv = tos, hot0 = tos, hot1 = tos, hot2 = tos, hot3 = tos;
+  if (a.y_ptr) yv = fr29_unpack(ld_fr(a.y_ptr));
+  if (a.hot[0] != EXPR_NO_SLOT) hot0 = fr29_unpack(ld_fr(a.cols[a.hot[0]] + row));
+  if (a.hot[1] != EXPR_NO_SLOT) hot1 = fr29_unpack(ld_fr(a.cols[a.hot[1]] + row));
+  if (a.hot[2] != EXPR_NO_SLOT) hot2 = fr29_unpack(ld_fr(a.cols[a.hot[2]] + row));
+  if (a.hot[3] != EXPR_NO_SLOT) hot3 = fr29_unpack(ld_fr(a.cols[a.hot[3]] + row));
+  uint32_t sp = 0;  // elements on the stack, including tos
+  const ExprInstr nop{0u, 0, nullptr};
+  const size_t blk_base = row & ~a.mask;
+  auto fetch = [&](const ExprInstr& in) -> Fr {
+    const size_t idx = blk_base + ((row + (size_t)(int64_t)in.rot) & a.mask);
+    return ld_fr(in.ptr + idx);
+  };
+  auto reads_col = [](uint32_t op) { return op_reads_col(op) || op == OP_ACC_MUL_COL; };
+  ExprInstr cur = a.prog_len > 0 ? a.prog[0] : nop;
+  ExprInstr nxt = a.prog_len > 1 ? a.prog[1] : nop;
+  Fr pre = reads_col(cur.op_arg >> 24) ? fetch(cur) : Fr::zero();
+  for (uint32_t pc = 0; pc < a.prog_len; pc++) {
+    const uint32_t op = cur.op_arg >> 24, arg = cur.op_arg & 0xffffffu;
+    const Fr v = pre;
+    const ExprInstr nn = pc + 2 < a.prog_len ? a.prog[pc + 2] : nop;
+    if (reads_col(nxt.op_arg >> 24)) pre = fetch(nxt);
+    switch (op) {
+      case OP_PUSH_COL:
+        if (sp > 0) lds_st29(stack, sp - 1, tid, tos);
+        tos = fr29_unpack(v);
+        sp++;
+        break;
+      case OP_MUL_COL:
+        tos = f29_mul(tos, fr29_unpack(v));
+        break;
+      case OP_ADD_COL:
+        tos = f29_add(tos, fr29_unpack(v));
+        break;
+      case OP_SUB_COL:
+        tos = f29_sub3(tos, fr29_unpack(v));
+        break;
+      case OP_PUSH_HOT:
+        if (sp > 0) lds_st29(stack, sp - 1, tid, tos);
+#pragma unroll
+        for (int i = 0; i < 9; i++) tos.l[i] = arg == 0 ? hot0.l[i] : arg == 1 ? hot1.l[i] : arg == 2 ? hot2.l[i] : hot3.l[i];
+        sp++;
+        break;
+      case OP_MUL_HOT:
+        if (arg == 0) tos = f29_mul(tos, hot0);
+        else if (arg == 1) tos = f29_mul(tos, hot1);
+        else if (arg == 2) tos = f29_mul(tos, hot2);
+        else tos = f29_mul(tos, hot3);
+        break;
+      case OP_PUSH_CONST:
+        if (sp > 0) lds_st29(stack, sp - 1, tid, tos);
+        tos = fr29_unpack(ld_fr(cur.ptr));
+        sp++;
+        break;
+      case OP_MUL_CONST:
+        tos = f29_mul(tos, fr29_unpack(ld_fr(cur.ptr)));
+        break;
+      case OP_ADD_CONST:
+        tos = f29_add(tos, fr29_unpack(ld_fr(cur.ptr)));
+        break;
+      case OP_ADD:
+        tos = f29_add(lds_ld29(stack, sp - 2, tid), tos);
+        sp--;
+        break;
+      case OP_SUB:
+        tos = f29_sub3(lds_ld29(stack, sp - 2, tid), tos);
+        sp--;
+        break;
+      case OP_SUB_BIG:
+        tos = f29_sub10(lds_ld29(stack, sp - 2, tid), tos);
+        sp--;
+        break;
+      case OP_MUL:
+        tos = f29_mul(lds_ld29(stack, sp - 2, tid), tos);
+        sp--;
+        break;
+      case OP_NEG:
+        tos = f29_neg3(tos);
+        break;
+      case OP_NEG_BIG:
+        tos = f29_neg10(tos);
+        break;
+      case OP_SQR:
+        tos = f29_sqr(tos);
+        break;
+      case OP_REDUCE:
+        tos = f29_reduce_weak(tos);
+        break;
+      case OP_ACC:  // h = h*y + value
+        h = f29_add(f29_mul(h, yv), tos);
+        sp--;
+        if (sp > 0) tos = lds_ld29(stack, sp - 1, tid);
+        break;
+      case OP_ACC_MUL_COL:
+        h = f29_mul2(h, yv, tos, fr29_unpack(v));
+        sp--;
+        if (sp > 0) tos = lds_ld29(stack, sp - 1, tid);
+        break;
+      case OP_ACC_MUL_CONST:
+        h = f29_mul2(h, yv, tos, fr29_unpack(ld_fr(cur.ptr)));
+        sp--;
+        if (sp > 0) tos = lds_ld29(stack, sp - 1, tid);
+        break;
+      case OP_ACC_MUL_HOT:
+        if (arg == 0) h = f29_mul2(h, yv, tos, hot0);
+        else if (arg == 1) h = f29_mul2(h, yv, tos, hot1);
+        else if (arg == 2) h = f29_mul2(h, yv, tos, hot2);
+        else h = f29_mul2(h, yv, tos, hot3);
+        sp--;
+        if (sp > 0) tos = lds_ld29(stack, sp - 1, tid);
+        break;
+      case OP_ACC_MUL:
+        h = f29_mul2(h, yv, lds_ld29(stack, sp - 2, tid), tos);
+        sp -= 2;
+        if (sp > 0) tos = lds_ld29(stack, sp - 1, tid);
+        break;
+      case OP_STORE:  // the host reduced tos below 2p
+        st_fr(a.outs[arg] + row, f29_pack_canonical<FrP>(tos));
+        sp--;
+        if (sp > 0) tos = lds_ld29(stack, sp - 1, tid);
+        break;
+      default:
+        break;
+    }
+    cur = nxt;
+    nxt = nn;
+  }
+  if (a.h_out) st_fr(a.h_out + row, f29_pack_canonical<FrP>(f29_reduce_weak(h)));
 }
 
 // ------------------------------------------------------------------------------ batch inversion
@@ -533,13 +683,17 @@ __global__ void scatter_rows_kernel(Fr* dst, size_t col_stride, size_t row0, con
 int zk_expr_eval(amdzk_ctx* ctx, const ExprArgs& a, uint32_t depth, const char* name) {
   size_t shmem = (size_t)(depth ? depth : 1) * EXPR_THREADS * sizeof(Fr);
   const dim3 grid((unsigned)((a.nrows + EXPR_THREADS - 1) / EXPR_THREADS)), block(EXPR_THREADS);
-  if (a.radix261) {
-    if (shmem > 65536) ZK_HIP(ctx, hipFuncSetAttribute((const void*)expr_eval_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    ZK_LAUNCH(ctx, name, expr_eval_kernel<true>, grid, block, shmem, a);
-  } else {
-    if (shmem > 65536) ZK_HIP(ctx, hipFuncSetAttribute((const void*)expr_eval_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    ZK_LAUNCH(ctx, name, expr_eval_kernel<false>, grid, block, shmem, a);
-  }
+  if (a.radix261) ZK_FAIL(ctx, AMDZK_E_INVALID, "expr_eval: radix-2^261 programs run on the limb-resident interpreter");
+  if (shmem > 65536) ZK_HIP(ctx, hipFuncSetAttribute((const void*)expr_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  ZK_LAUNCH(ctx, name, expr_eval_kernel, grid, block, shmem, a);
+  return AMDZK_OK;
+}
+
+int zk_expr_eval_limbs(amdzk_ctx* ctx, const ExprArgs& a, uint32_t depth, const char* name) {
+  size_t shmem = (size_t)(depth ? depth : 1) * EXPR_THREADS * 9 * sizeof(uint32_t);
+  const dim3 grid((unsigned)((a.nrows + EXPR_THREADS - 1) / EXPR_THREADS)), block(EXPR_THREADS);
+  if (shmem > 65536) ZK_HIP(ctx, hipFuncSetAttribute((const void*)expr_eval_limbs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+  ZK_LAUNCH(ctx, name, expr_eval_limbs_kernel, grid, block, shmem, a);
   return AMDZK_OK;
 }
 

@@ -23,6 +23,15 @@ enum ExprOp : uint32_t {
   OP_SQR = 14,
   OP_PUSH_HOT = 15,  // push hot[arg]
   OP_MUL_HOT = 16,   // tos *= hot[arg]
+  // ---- only in programs finalised for the limb-resident interpreter (expr_eval_limbs_kernel, radix 2^261): values
+  // stay on 9 x 29-bit limbs, lazily reduced; the host tracks each value's bound and places the reductions
+  OP_REDUCE = 17,       // tos = weak reduction of tos (below 1.0002 p)
+  OP_SUB_BIG = 18,      // as OP_SUB with a subtrahend (tos) between 2p and 9p
+  OP_NEG_BIG = 19,      // as OP_NEG with tos between 2p and 9p
+  OP_ACC_MUL_COL = 20,  // h = h*y + tos * column   (one Montgomery reduction for both products)
+  OP_ACC_MUL_CONST = 21,
+  OP_ACC_MUL_HOT = 22,
+  OP_ACC_MUL = 23,      // h = h*y + stack[sp-2] * tos
 };
 
 constexpr int EXPR_HOT = 4;
@@ -54,6 +63,8 @@ struct ExprArgs {
 };
 
 int zk_expr_eval(amdzk_ctx* ctx, const ExprArgs& a, uint32_t depth, const char* name);
+// the same for a radix-2^261 program finalised by the host for the limb-resident interpreter (prover.hip finalize_limb_program)
+int zk_expr_eval_limbs(amdzk_ctx* ctx, const ExprArgs& a, uint32_t depth, const char* name);
 int zk_batch_invert(amdzk_ctx* ctx, bn254::Fr* d_a, bn254::Fr* d_scratch, size_t total);
 int zk_mul_elem(amdzk_ctx* ctx, bn254::Fr* d_a, const bn254::Fr* d_b, size_t total);
 size_t zk_scan_totals_elems(size_t n, size_t ncols);

@@ -437,6 +437,126 @@ int emit_compressed(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, uint32_t first, u
   return AMDZK_OK;
 }
 
+// Quotient-domain programs run on the limb-resident interpreter (plonk_kernels.hip expr_eval_limbs_kernel): values are
+// 9 x 29-bit limbs, lazily reduced. This pass walks the (straight-line, wave-uniform) program once with the bound of
+// every stack entry in units of p and
+//   * inserts OP_REDUCE where a product would leave f29_mul's range (a*b < 169 p^2), where a subtrahend is too large
+//     for the K*p constants (below 2p: K = 3, below 9p: K = 10), before a value sinks into the LDS stack with a bound
+//     above 8, and before OP_STORE (packing needs a value below 2p);
+//   * picks OP_SUB / OP_SUB_BIG and OP_NEG / OP_NEG_BIG by the subtrahend's bound;
+//   * fuses `tos = tos * x; h = h*y + tos` into one two-product reduction (OP_ACC_MUL_*).
+// Bounds: a column, constant or hot value is below 1 (canonical); a product is below 2; a sum adds the bounds; a
+// difference a - b adds K to a's; the weak reduction gives 1.0002.
+void finalize_limb_program(Program& pr) {
+  std::vector<uint32_t> out;
+  std::vector<double> st;  // bounds, st.back() = top of stack
+  double hb = 0.0;         // bound of the accumulator h
+  const double LIM = 160.0, RED = 1.01;
+  size_t last_mul = (size_t)-1;  // index in `out` of a product that made the current top of stack, if it is the last op
+  double mul_a = 0, mul_b = 0;   // its operands' bounds
+  auto emit = [&](uint32_t op, uint32_t arg = 0) { out.push_back((op << 24) | (arg & 0xffffffu)); };
+  auto reduce_tos = [&]() {
+    emit(OP_REDUCE);
+    st.back() = RED;
+  };
+  uint32_t depth = 0;
+  for (uint32_t w : pr.words) {
+    const uint32_t op = w >> 24, arg = w & 0xffffffu;
+    const bool was_mul = last_mul == out.size() - 1 && !out.empty();
+    size_t this_mul = (size_t)-1;
+    switch (op) {
+      case OP_PUSH_COL:
+      case OP_PUSH_CONST:
+      case OP_PUSH_HOT:
+        if (!st.empty() && st.back() > 8.0) reduce_tos();
+        emit(op, arg);
+        st.push_back(1.0);
+        break;
+      case OP_MUL_COL:
+      case OP_MUL_CONST:
+      case OP_MUL_HOT:
+        if (st.back() >= LIM) reduce_tos();
+        mul_a = st.back();
+        mul_b = 1.0;
+        emit(op, arg);
+        this_mul = out.size() - 1;
+        st.back() = 2.0;
+        break;
+      case OP_ADD_COL:
+      case OP_ADD_CONST:
+        if (st.back() + 1.0 > 40.0) reduce_tos();
+        emit(op, arg);
+        st.back() += 1.0;
+        break;
+      case OP_SUB_COL:
+        if (st.back() + 3.0 > 40.0) reduce_tos();
+        emit(op, arg);
+        st.back() += 3.0;
+        break;
+      case OP_ADD: {
+        if (st[st.size() - 2] + st.back() > 40.0) reduce_tos();
+        const double b = st.back();
+        st.pop_back();
+        emit(op);
+        st.back() += b;
+      } break;
+      case OP_SUB: {
+        if (st.back() >= 9.0) reduce_tos();
+        const double b = st.back();
+        st.pop_back();
+        emit(b < 2.0 ? OP_SUB : OP_SUB_BIG);
+        st.back() += b < 2.0 ? 3.0 : 10.0;
+      } break;
+      case OP_MUL: {
+        if (st[st.size() - 2] * st.back() >= LIM) reduce_tos();
+        mul_b = st.back();
+        st.pop_back();
+        mul_a = st.back();
+        emit(op);
+        this_mul = out.size() - 1;
+        st.back() = 2.0;
+      } break;
+      case OP_NEG:
+        if (st.back() >= 9.0) reduce_tos();
+        emit(st.back() < 2.0 ? OP_NEG : OP_NEG_BIG);
+        st.back() = st.back() < 2.0 ? 3.0 : 10.0;
+        break;
+      case OP_SQR:
+        if (st.back() * st.back() >= LIM) reduce_tos();
+        emit(op);
+        st.back() = 2.0;
+        break;
+      case OP_ACC:
+        if (was_mul && hb + mul_a * mul_b < LIM) {  // h*y + a*b in one reduction
+          const uint32_t mw = out.back();
+          out.pop_back();
+          const uint32_t mop = mw >> 24;
+          emit(mop == OP_MUL_COL ? OP_ACC_MUL_COL : mop == OP_MUL_CONST ? OP_ACC_MUL_CONST : mop == OP_MUL_HOT ? OP_ACC_MUL_HOT : OP_ACC_MUL,
+               mw & 0xffffffu);
+          hb = 2.0;
+        } else {
+          if (2.0 + st.back() > 40.0) reduce_tos();
+          emit(op);
+          hb = 2.0 + st.back();
+        }
+        st.pop_back();
+        break;
+      case OP_STORE:
+        if (st.back() >= 2.0) reduce_tos();
+        emit(op, arg);
+        st.pop_back();
+        break;
+      default:
+        emit(op, arg);
+        break;
+    }
+    last_mul = this_mul;
+    if (st.size() > depth) depth = (uint32_t)st.size();
+  }
+  pr.words.swap(out);
+  pr.depth = depth + 1;  // OP_ACC_MUL reads two entries below the former product: keep one spare slot
+}
+
 // d_consts261[i] = 32 * consts[i] in the ordinary form, i.e. consts[i] in radix 2^261 (a few hundred values).
 int upload_consts261(amdzk_ctx* ctx, amdzk_pk* pk) {
   Fr k32 = Fr::one();
@@ -459,11 +579,11 @@ int upload_program(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, bool extended) {
     ins[i].op_arg = w;
     ins[i].rot = 0;
     ins[i].ptr = nullptr;
-    if (op == OP_PUSH_COL || op == OP_MUL_COL || op == OP_ADD_COL || op == OP_SUB_COL) {
+    if (op == OP_PUSH_COL || op == OP_MUL_COL || op == OP_ADD_COL || op == OP_SUB_COL || op == OP_ACC_MUL_COL) {
       if ((arg >> 8) >= cols.size() || (arg & 0xff) >= pk->rots.rots.size()) ZK_FAIL(ctx, AMDZK_E_INVALID, "program: bad column operand");
       ins[i].ptr = cols[arg >> 8];
       ins[i].rot = pk->rots.rots[arg & 0xff];  // rows of one coset are consecutive: a rotation is a row offset in both domains
-    } else if (op == OP_PUSH_CONST || op == OP_MUL_CONST || op == OP_ADD_CONST) {
+    } else if (op == OP_PUSH_CONST || op == OP_MUL_CONST || op == OP_ADD_CONST || op == OP_ACC_MUL_CONST) {
       if (arg >= pk->consts.size()) ZK_FAIL(ctx, AMDZK_E_INVALID, "program: bad constant operand");
       ins[i].ptr = (extended ? pk->d_consts261 : pk->d_consts) + arg;
     }
@@ -495,7 +615,7 @@ int run_program(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, bool extended, Fr* co
     a.hot[2] = pk->se_lactive();
     a.hot[3] = pk->se_x();
   }
-  return zk_expr_eval(ctx, a, pr.depth + 1, name);
+  return extended ? zk_expr_eval_limbs(ctx, a, pr.depth + 1, name) : zk_expr_eval(ctx, a, pr.depth + 1, name);
 }
 
 Fr rotate_omega(const amdzk_pk* pk, const Fr& x, int rot) {
@@ -1017,6 +1137,7 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
   KG_TRY(upload_program(ctx, pk, pk->prog_compress, false));
   KG_TRY(upload_program(ctx, pk, pk->prog_pfrac, false));
   KG_TRY(upload_program(ctx, pk, pk->prog_lfrac, false));
+  finalize_limb_program(pk->prog_h);
   KG_TRY(upload_program(ctx, pk, pk->prog_h, true));
   if (getenv("AMDZK_DUMP_PROG")) {  // debugging aid: what the compiled h(X) program is made of
     static const char* names[] = {"END", "PUSH_COL", "PUSH_CONST", "ADD", "SUB", "MUL", "NEG", "MUL_CONST", "ADD_CONST", "MUL_COL",
@@ -1048,6 +1169,7 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
     pr.op(OP_SUB_COL, COL(pk->se_llast(), r0));
     pr.op(OP_SUB_COL, COL(pk->se_lactive(), r0));
     pr.op(OP_STORE, 0); pr.pop();
+    finalize_limb_program(pr);
     KG_TRY(upload_program(ctx, pk, pr, true));
     Fr** d_out = nullptr;
     KG_TRY(dalloc(ctx, pk, &d_out, 1));
