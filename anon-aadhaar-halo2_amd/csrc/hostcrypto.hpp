@@ -344,6 +344,13 @@ class ChaCha20Rng {
     for (int i = 0; i < 8; i++) l[i] = next_u64();
     return fr_from_u512(l);
   }
+  // Every draw this prover makes is an Fr::random = 8 x next_u64 = exactly one 64-byte ChaCha block, so between draws
+  // the stream sits on a block boundary: draw number j is block j of the key stream. That lets a run of draws (the
+  // n coefficients of vanishing::prover's random polynomial) be produced on the device, block j0 + i by thread i.
+  bool at_block_boundary() const { return pos_ == 16; }
+  uint64_t block_counter() const { return counter_; }
+  const uint32_t* key() const { return key_; }
+  void skip_blocks(uint64_t nblocks) { counter_ += nblocks; }
 
  private:
   uint32_t key_[8], buf_[16];

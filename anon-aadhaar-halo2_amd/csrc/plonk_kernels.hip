@@ -302,6 +302,45 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_limbs_kernel(ExprArgs 
   if (a.h_out) st_fr(a.h_out + row, f29_pack_canonical<FrP>(f29_reduce_weak(h)));
 }
 
+// ------------------------------------------------------------------------------ Fr::random on the device
+// vanishing::prover::Argument::commit draws the n coefficients of its random polynomial one Fr::random at a time: 8 x
+// next_u64 of ChaCha20Rng = one 64-byte ChaCha20 block each (block counter in words 12-13, nonce 0), reduced from
+// 512 bits with halo2curves' from_u512: d0 * R^2 + d1 * R^3 in Montgomery arithmetic (d0, d1 the two 256-bit
+// halves; bn254.cuh's product accepts a second operand up to 2^256). Thread i produces draw counter0 + i — the same
+// values, in the same order, as the host loop this replaces (hostcrypto.hpp ChaCha20Rng::fr, 2.9 ms per proof).
+struct ChaChaKey {
+  uint32_t k[8];
+};
+__global__ __launch_bounds__(256) void chacha20_fr_random_kernel(Fr* out, size_t n, ChaChaKey key, uint64_t counter0, Fr r3) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t ctr = counter0 + i;
+  uint32_t c[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key.k[0], key.k[1], key.k[2], key.k[3], key.k[4], key.k[5], key.k[6], key.k[7],
+                    (uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+  uint32_t x[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) x[j] = c[j];
+  auto rotl = [](uint32_t v, int s) { return (v << s) | (v >> (32 - s)); };
+#define CQR(a, b, cc, d)                        \
+  x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16);   \
+  x[cc] += x[d]; x[b] = rotl(x[b] ^ x[cc], 12); \
+  x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8);    \
+  x[cc] += x[d]; x[b] = rotl(x[b] ^ x[cc], 7);
+#pragma unroll 1
+  for (int r = 0; r < 10; r++) {
+    CQR(0, 4, 8, 12) CQR(1, 5, 9, 13) CQR(2, 6, 10, 14) CQR(3, 7, 11, 15)
+    CQR(0, 5, 10, 15) CQR(1, 6, 11, 12) CQR(2, 7, 8, 13) CQR(3, 4, 9, 14)
+  }
+#undef CQR
+  Fr d0, d1;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    d0.l[j] = x[j] + c[j];
+    d1.l[j] = x[8 + j] + c[8 + j];
+  }
+  st_fr(out + i, add(mul(Fr::r2(), d0), mul(r3, d1)));
+}
+
 // ------------------------------------------------------------------------------ batch inversion
 // In place over a flat array; zeros stay zero (ff::BatchInvert). One Fermat inversion per chunk.
 __global__ __launch_bounds__(256) void batch_invert_kernel(Fr* a, Fr* scratch, size_t total, uint32_t chunk) {
@@ -694,6 +733,13 @@ int zk_expr_eval_limbs(amdzk_ctx* ctx, const ExprArgs& a, uint32_t depth, const 
   const dim3 grid((unsigned)((a.nrows + EXPR_THREADS - 1) / EXPR_THREADS)), block(EXPR_THREADS);
   if (shmem > 65536) ZK_HIP(ctx, hipFuncSetAttribute((const void*)expr_eval_limbs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   ZK_LAUNCH(ctx, name, expr_eval_limbs_kernel, grid, block, shmem, a);
+  return AMDZK_OK;
+}
+
+int zk_chacha20_fr_random(amdzk_ctx* ctx, Fr* d_out, size_t n, const uint32_t key[8], uint64_t counter0, const Fr& r3) {
+  ChaChaKey k;
+  memcpy(k.k, key, sizeof(k.k));
+  if (n) ZK_LAUNCH(ctx, "chacha20_fr_random", chacha20_fr_random_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_out, n, k, counter0, r3);
   return AMDZK_OK;
 }
 

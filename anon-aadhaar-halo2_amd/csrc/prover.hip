@@ -1432,11 +1432,18 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
   tick("lookup_products");
   // 5. vanishing: random polynomial (coefficient form), commit with g
   {
-    std::vector<Fr> rp(n);
-    for (auto& v : rp) v = rng.fr();
+    if (rng.rng && rng.rng->at_block_boundary()) {
+      // ChaCha20Rng: draw j of the stream is key-stream block j, so the n coefficients come from one kernel
+      ZK_TRY(zk_chacha20_fr_random(ctx, pk->rnd, n, rng.rng->key(), rng.rng->block_counter(), zkhost::fr_r3()));
+      rng.rng->skip_blocks(n);
+    } else {  // the caller's own RngCore: its pre-drawn scalars
+      std::vector<Fr> rp(n);
+      for (auto& v : rp) v = rng.fr();
+      ZK_TRY(h2d_staged(ctx, pk, pk->rnd, rp.data(), n * 32));
+      if (!pk->pin || n * 32 > pk->pin_cap) ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `rp` is a temporary
+    }
     (void)rng.fr();
-    tick("  random: host rng");
-    ZK_TRY(h2d_staged(ctx, pk, pk->rnd, rp.data(), n * 32));
+    tick("  random: rng");
     std::vector<G1Affine> cm;
     ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G, pk->rnd, 1, cm));
     ZK_TRY(write_points(cm, "random_poly"));
