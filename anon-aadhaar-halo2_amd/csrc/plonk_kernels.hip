@@ -460,9 +460,12 @@ __global__ __launch_bounds__(256) void poly_eval_kernel(const Fr* const* polys, 
   Fr s = Fr::zero();
   if (t < n) {
     uint32_t top = (n - 1 - t) / 256;  // largest j with t + 256 j < n
-    s = ld_fr(p + t + 256u * top);
-    const Fr x256r = fr29_const_to_r261(x256);  // the Horner multiplier, radix 2^261 (mixed-radix product)
-    for (uint32_t j = top; j-- > 0;) s = add(fr29_mul_const(s, x256r), ld_fr(p + t + 256u * j));
+    // Horner on limbs: the multiplier in radix 2^261 (mixed-radix product: data stays in the ordinary form), the
+    // running value lazily reduced — a product (< 2p) plus a canonical coefficient stays below 3p
+    const Fr29 x256r = fr29_unpack(fr29_const_to_r261(x256));
+    Fr29 acc = fr29_unpack(ld_fr(p + t + 256u * top));
+    for (uint32_t j = top; j-- > 0;) acc = f29_add(f29_mul(acc, x256r), fr29_unpack(ld_fr(p + t + 256u * j)));
+    s = f29_pack_canonical<FrP>(f29_reduce_weak(acc));
     s = mul(s, pow_u64(x, t));
   }
   red[t] = s;

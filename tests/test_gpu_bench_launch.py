@@ -1,0 +1,31 @@
+"""GPU: `python bench.py --gpus 2` end to end with the REAL prover — launcher, two ranks, rendezvous, barriers,
+max-over-ranks timing, the gather of the proofs and its check, one JSON line from rank 0. Both ranks share the box's
+one GPU (AMDZK_BENCH_FORCE_DEVICE=0) and the collective backend is gloo: two NCCL ranks cannot sit on one device.
+On the driver's 8-GPU node the same code runs with one GPU per rank over RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_on_one_gpu_batch_mode():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update({"AMDZK_BENCH_FORCE_DEVICE": "0", "AMDZK_BENCH_BACKEND": "gloo"})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "8", "--shape", "k15", "--warmup", "1",
+                        "--concurrency", "2", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    ln = lines[0]
+    assert ln["n_gpus"] == 2 and ln["steps"] == 4 and ln["config"]["batch"] == 8 and ln["config"]["proofs_total"] == 8
+    assert ln["data"] == "synthetic" and ln["config"]["proof_bytes"] == 34976
+    assert "all_gather of 8 proofs" in ln["config"]["gather"]
+    assert ln["config"]["pcie_inclusive_proofs_per_s"] > 0  # the streamed pass ran and its proofs equalled the resident ones
+    assert ln["roofline"]["kernel"].startswith("msm") and ln["value"] > 1.0
