@@ -470,12 +470,13 @@ def roofline(prover, desc):
 
 
 def kernel_src_hash():
-    """sha256 over the kernel sources (csrc/*.hip, *.cuh, *.hpp), the same way tools/summarize_prof.py stamps a PMC
+    """sha256 over the kernel sources (csrc/*.hip, *.cuh, *.hpp, *.inc and the Makefile with its flags), the same way tools/summarize_prof.py stamps a PMC
     summary: counters measured on other kernel code are not this build's counters."""
     import glob
     h = hashlib.sha256()
     d = os.path.join(ROOT, "anon-aadhaar-halo2_amd", "csrc")
-    for p in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.cuh")) + glob.glob(os.path.join(d, "*.hpp"))):
+    for p in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.cuh")) + glob.glob(os.path.join(d, "*.hpp")) +
+                    glob.glob(os.path.join(d, "*.inc")) + [os.path.join(d, "Makefile")]):
         h.update(os.path.basename(p).encode() + b"\0")
         h.update(open(p, "rb").read())
     return h.hexdigest()[:16]
