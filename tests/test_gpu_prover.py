@@ -72,6 +72,41 @@ def test_unsatisfied_witness_does_not_verify(ctx, pkg, plonk, oracle):
     d_adv.free(); pk.free(); params.free()
 
 
+def test_quotient_coset_modes(ctx, pkg, plonk, oracle, monkeypatch):
+    """The quotient is computed on cs_degree - 1 cosets of the size-n subgroup; AMDZK_FULL_COSETS=1
+    (read at keygen) uses all 2^(ek-k), which is upstream's own extended-domain computation. For a satisfying witness
+    both give the oracle's bytes. For a witness that does NOT satisfy the circuit the numerator is not divisible by
+    X^n - 1: the full mode still reproduces the oracle's (= upstream's) bytes, the default mode interpolates a
+    different polynomial — and neither proof verifies."""
+    small = dict(k=7, num_advice=5, num_lookup_advice=2, lookup_bits=5, num_spread=2, spread_bits=3)
+    good = circuits.rsa_sha256_shape(plonk, **small)  # degree 4: 3 of the 4 cosets by default
+    bad = circuits.rsa_sha256_shape(plonk, **small)
+    assert good.desc["cs_degree"] == 4
+    bad.advice[0][3] = (bad.advice[0][3] + 1) % zu.R  # break the first vertical gate's output cell
+    with pytest.raises(AssertionError):
+        circuits.check_satisfied(bad, rows=range(4))
+    proofs = {}
+    for mode in ("default", "full"):
+        if mode == "full":
+            monkeypatch.setenv("AMDZK_FULL_COSETS", "1")
+        else:
+            monkeypatch.delenv("AMDZK_FULL_COSETS", raising=False)
+        for name, c in (("good", good), ("bad", bad)):
+            params, pk, d_adv, inst = setup(ctx, pkg, plonk, oracle, c)
+            proofs[(mode, name)] = plonk.create_proof(ctx, pk, inst, d_adv, seed=21)
+            d_adv.free(); pk.free(); params.free()
+    monkeypatch.delenv("AMDZK_FULL_COSETS", raising=False)
+    opk = PR.keygen(good.desc, good.fixed, good.assembly.mapping, TAU, transcript_repr=123456789)
+    want_good = PR.create_proof(opk, good.instances, good.advice, seed=21)
+    want_bad = PR.create_proof(opk, bad.instances, bad.advice, seed=21)
+    assert proofs[("default", "good")] == want_good and proofs[("full", "good")] == want_good
+    assert proofs[("full", "bad")] == want_bad
+    assert proofs[("default", "bad")] != want_bad
+    for mode in ("default", "full"):
+        with pytest.raises(AssertionError):
+            PR.verify_proof(opk, bad.instances, proofs[(mode, "bad")])
+
+
 def test_lookup_failure_is_reported(ctx, pkg, plonk, oracle):
     c = circuits.lookup_circuit(plonk, 5, seed=4)
     rows = [r for r in range(c.usable) if c.fixed[2][r] == 1]  # fixed[2] = q_rng: range lookup enabled
