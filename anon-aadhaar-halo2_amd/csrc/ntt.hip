@@ -202,8 +202,8 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
       Fr29 sum = f29_add(u, v);
       if (reduce_sums) sum = f29_reduce_weak(sum);
       lds_st(L, e0, sum);
-      Fr29 d = f29_sub10(u, v);  // below bound(u) + 10
-      if (st > 0) d = f29_mul(d, lds_ld(TW, i << (a.s - 1 - st)));
+      // below bound(u) + 10; where a twiddle product follows, the difference enters it without its carry pass
+      const Fr29 d = st > 0 ? f29_mul(f29_sub10_lazy(u, v), lds_ld(TW, i << (a.s - 1 - st))) : f29_sub10(u, v);
       lds_st(L, e1, d);
     }
     __syncthreads();

@@ -54,6 +54,10 @@ int main() {
       Fq r8v = sub(x, add(add(y, y), add(y, y))), t12v = sub(z, add(add(w, w), add(w, w))), y5v = add(add(z, z), add(z, w));
       if (!eq(fq29_to_r256(f29_mul2(r8, t12, f29_neg6(y5), b)), sub(mul(r8v, t12v), mul(y5v, y)))) { fails++; printf("mul2 lazy\n"); }
       if (!eq(fq29_to_r256(f29_sqr(t12)), sqr(t12v))) { fails++; printf("sqr lazy\n"); }
+      // the un-carried difference as one operand of a product / of the two-product reduction
+      Fq29 tl = f29_sub10_lazy(c, f29_add(f29_add(d, d), f29_add(d, d)));
+      if (!eq(fq29_to_r256(f29_mul(tl, b)), mul(t12v, y))) { fails++; printf("mul with lazy difference\n"); }
+      if (!eq(fq29_to_r256(f29_mul2(r8, tl, f29_neg6(y5), b)), sub(mul(r8v, t12v), mul(y5v, y)))) { fails++; printf("mul2 with lazy difference\n"); }
     }
     if (fails > 5) return 1;
   }
