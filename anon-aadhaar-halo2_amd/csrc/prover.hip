@@ -1852,6 +1852,32 @@ int amdzk_pk_inspect(amdzk_ctx* ctx, const amdzk_pk* pk, int what, uint64_t* out
   return AMDZK_OK;
 }
 
+// Test hooks for the host pass that prepares quotient-domain programs for the limb-resident interpreter
+// (finalize_limb_program): (a) the pass on caller-supplied program words — pure host code, no device — and (b) the
+// finalised h(X) program of a key. Words are `op << 24 | arg` with the opcodes of csrc/plonk_kernels.hpp.
+int amdzk_debug_limb_program(const uint32_t* words, size_t n, uint32_t* out, size_t cap, size_t* out_n, uint32_t* depth) {
+  if ((!words && n) || !out_n) return AMDZK_E_INVALID;
+  Program pr;
+  pr.words.assign(words, words + n);
+  finalize_limb_program(pr);
+  *out_n = pr.words.size();
+  if (depth) *depth = pr.depth;
+  if (out) {
+    if (cap < pr.words.size()) return AMDZK_E_INVALID;
+    memcpy(out, pr.words.data(), pr.words.size() * sizeof(uint32_t));
+  }
+  return AMDZK_OK;
+}
+int amdzk_pk_h_program(const amdzk_pk* pk, uint32_t* out, size_t cap, size_t* out_n) {
+  if (!pk || !out_n) return AMDZK_E_INVALID;
+  *out_n = pk->prog_h.words.size();
+  if (out) {
+    if (cap < pk->prog_h.words.size()) return AMDZK_E_INVALID;
+    memcpy(out, pk->prog_h.words.data(), pk->prog_h.words.size() * sizeof(uint32_t));
+  }
+  return AMDZK_OK;
+}
+
 // lookup::prover::permute_expression_pair for nlookups (input, table) pairs of n rows each, Montgomery form,
 // column l at + l * n: d_inputs is sorted in place into A', d_permuted_tables_out receives S'; rows >= usable of both
 // are zero. Fails with "not in table" when an input value is missing from its table.

@@ -91,6 +91,8 @@ def lib():
         "amdzk_permute_expression_pair_dev": (i32, [vp, vp, vp, vp, sz, u32, u32]),
         "amdzk_quotient_eval_dev": (i32, [vp, vp, vp, sz, vp, vp, vp, vp, vp]),
         "amdzk_pk_inspect": (i32, [vp, vp, i32, vp, sz, C.POINTER(sz)]),
+        "amdzk_debug_limb_program": (i32, [vp, sz, vp, sz, C.POINTER(sz), C.POINTER(u32)]),
+        "amdzk_pk_h_program": (i32, [vp, vp, sz, C.POINTER(sz)]),
         "amdzk_timer_start": (i32, [vp]),
         "amdzk_timer_stop": (i32, [vp, C.POINTER(C.c_float)]),
         "amdzk_prof_enable": (i32, [vp, i32]),

@@ -294,6 +294,13 @@ int amdzk_quotient_eval_dev(amdzk_ctx* ctx, amdzk_pk* pk, const void* d_polys, s
  * out may be NULL to query *count (in Fr elements). */
 int amdzk_pk_inspect(amdzk_ctx* ctx, const amdzk_pk* pk, int what, uint64_t* out, size_t cap, size_t* count);
 
+/* Test hooks for the host pass that prepares quotient-domain programs for the limb-resident interpreter (bounds in
+ * units of p, placement of the weak reductions, fusion of `t*x` with the accumulate): the pass on caller-supplied words
+ * `op << 24 | arg` (opcodes: csrc/plonk_kernels.hpp ExprOp) — pure host code, callable without a device — and the
+ * finalised h(X) program of a key. out may be NULL to query *out_n. */
+int amdzk_debug_limb_program(const uint32_t* words, size_t n, uint32_t* out, size_t cap, size_t* out_n, uint32_t* depth);
+int amdzk_pk_h_program(const amdzk_pk* pk, uint32_t* out, size_t cap, size_t* out_n);
+
 /* ---- timing / profiling hooks used by bench.py (HIP events on this ctx's stream) ------------ */
 int amdzk_timer_start(amdzk_ctx* ctx);
 int amdzk_timer_stop(amdzk_ctx* ctx, float* ms); /* synchronises on the stop event */

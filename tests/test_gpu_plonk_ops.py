@@ -313,3 +313,39 @@ def test_quotient_identity_and_product_columns(ctx, pkg, oracle, which):
         assert all(a_rows[r] == s_rows[r] or a_rows[r] == a_rows[r - 1] for r in range(1, usable)) and a_rows[0] == s_rows[0]
     res["pk"].free()
     params.free()
+
+
+def test_h_program_of_the_metric_shape_respects_every_bound(ctx, pkg, oracle):
+    """The finalised h(X) program of the metric's constraint system (141 advice, 24 lookups, 118 permutation columns —
+    the program depends on the shape, not on k, so k = 10 keeps keygen short) walked by the independent bound checker:
+    every product within a*b < 169 p^2, every difference with an adequate K*p, nothing stored above 2p; and the
+    accumulate fused into (nearly) every term."""
+    import ctypes as C
+
+    import limb_program_check as LC
+
+    plonk = pkg.plonk
+    shape = dict(circuits.SHAPES["full"])
+    shape.pop("composite")
+    shape["k"] = 10
+    c = circuits.full_aadhaar_shape(plonk, **shape)
+    assert c.desc["num_advice"] == 141 and len(c.desc["lookups"]) == 24 and len(c.desc["permutation_columns"]) == 118
+    params = pkg.kzg.ParamsKZG.setup(ctx, c.k, zu.fr_from_int(TAU))
+    fixed = np.stack([zu.ints_to_fr(oracle, col) for col in c.fixed])
+    pk = plonk.ProvingKey(ctx, params, c.desc, fixed, c.assembly.mapping, zu.fr_from_int(99))
+    n = C.c_size_t(0)
+    assert pkg.lib().amdzk_pk_h_program(pk.h, None, 0, C.byref(n)) == 0
+    words = np.zeros(n.value, dtype=np.uint32)
+    assert pkg.lib().amdzk_pk_h_program(pk.h, words.ctypes.data, n.value, C.byref(n)) == 0
+    words = [int(w) for w in words]
+    depth, nred, nfused = LC.check(words)
+    names = [LC.NAME[w >> 24] for w in words]
+    nterms = nfused + names.count("ACC")
+    # gates: 80 vertical + 12 identity polynomials + 1 square; permutation: 2 + (nsets - 1) + nsets terms with
+    # nsets = 118 / (degree - 2) = 59; lookups: 5 per lookup
+    nsets = (118 + c.desc["cs_degree"] - 3) // (c.desc["cs_degree"] - 2)
+    assert nterms == 93 + (2 + nsets - 1 + nsets) + 5 * 24
+    assert nfused >= nterms - 2, "the accumulate should be fused into (nearly) every term: %d of %d" % (nfused, nterms)
+    assert depth <= 4
+    pk.free()
+    params.free()
