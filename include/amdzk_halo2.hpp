@@ -657,6 +657,65 @@ inline std::vector<uint8_t> create_proof(const Context& ctx, const ProvingKey& p
   return proof;
 }
 
+// One witness per proof from the host (what a caller does after Circuit::synthesize, /root/reference/src/lib.rs:328-397):
+// the advice columns are synthesized into pinned memory, and the upload of proof i+1's witness runs on the ctx's copy
+// stream while proof i is proved (amdzk_dev_upload_async / amdzk_upload_fence; double-buffered device staging).
+class WitnessStream {
+ public:
+  WitnessStream(const Context& ctx, const ProvingKey& pk) : ctx_(ctx), pk_(pk), n_((size_t)1 << pk.k()) {
+    bytes_ = std::max<size_t>(1, pk.num_advice()) * n_ * sizeof(Fr);
+    for (int i = 0; i < 2; i++) {
+      ctx_.check(amdzk_dev_alloc(ctx_.get(), bytes_, &dev_[i]));
+      ctx_.check(amdzk_host_alloc(ctx_.get(), bytes_, &pin_[i]));
+    }
+  }
+  ~WitnessStream() {
+    for (int i = 0; i < 2; i++) {
+      if (dev_[i]) amdzk_dev_free(ctx_.get(), dev_[i]);
+      if (pin_[i]) amdzk_host_free(ctx_.get(), pin_[i]);
+    }
+  }
+  WitnessStream(const WitnessStream&) = delete;
+  WitnessStream& operator=(const WitnessStream&) = delete;
+
+  // create_proof for every (advice, instances, seed) of the batch, in order.
+  struct Item {
+    const std::vector<std::vector<Fr>>* advice;
+    const std::vector<std::vector<Fr>>* instances;
+    uint64_t rng_seed;
+  };
+  std::vector<std::vector<uint8_t>> prove(const std::vector<Item>& items, Transcript transcript = Transcript::Blake2b,
+                                          Multiopen multiopen = Multiopen::Shplonk) {
+    std::vector<std::vector<uint8_t>> out;
+    if (items.empty()) return out;
+    stage(0, *items[0].advice);
+    for (size_t j = 0; j < items.size(); j++) {
+      const int cur = (int)(j & 1);
+      ctx_.check(amdzk_upload_fence(ctx_.get()));                    // proof j's witness is (being) uploaded: order the proof behind it
+      if (j + 1 < items.size()) stage(cur ^ 1, *items[j + 1].advice);  // proof j-1, the last reader of that buffer, has returned
+      out.push_back(create_proof(ctx_, pk_, *items[j].instances, dev_[cur], n_, items[j].rng_seed, transcript, multiopen));
+    }
+    return out;
+  }
+
+ private:
+  void stage(int slot, const std::vector<std::vector<Fr>>& advice) {
+    if (advice.size() != pk_.num_advice()) throw Error(AMDZK_E_INVALID, "WitnessStream: advice column count");
+    Fr* h = (Fr*)pin_[slot];
+    for (size_t c = 0; c < advice.size(); c++) {
+      if (advice[c].size() > n_) throw Error(AMDZK_E_INVALID, "WitnessStream: advice column longer than 2^k");
+      std::copy(advice[c].begin(), advice[c].end(), h + c * n_);
+      std::fill(h + c * n_ + advice[c].size(), h + (c + 1) * n_, Fr::zero());
+    }
+    ctx_.check(amdzk_dev_upload_async(ctx_.get(), dev_[slot], pin_[slot], bytes_));
+  }
+  const Context& ctx_;
+  const ProvingKey& pk_;
+  size_t n_, bytes_ = 0;
+  void* dev_[2] = {nullptr, nullptr};
+  void* pin_[2] = {nullptr, nullptr};
+};
+
 }  // namespace halo2
 }  // namespace amdzk
 #endif /* AMDZK_HALO2_HPP */

@@ -240,6 +240,16 @@ static int prove(int argc, char** argv) {
   std::cout << "proof ";
   for (uint8_t b : proof) std::printf("%02x", b);
   std::cout << '\n';
+  {  // the same witness through the streaming path, three proofs with seeds seed, seed + 1, seed + 2 (both staging buffers used twice)
+    WitnessStream ws(ctx, pk);
+    std::vector<WitnessStream::Item> items;
+    for (uint64_t j = 0; j < 3; j++) items.push_back({&advice, &instances, seed + j});
+    for (const auto& pr : ws.prove(items, tr, mo)) {
+      std::cout << "streamed ";
+      for (uint8_t b : pr) std::printf("%02x", b);
+      std::cout << '\n';
+    }
+  }
   // ParamsKZG surface: commit of the first advice column in both bases (checked by the caller)
   std::vector<G1Affine> fc, pc;
   pk.commitments(fc, pc);

@@ -101,3 +101,8 @@ def test_cpp_driven_proof_equals_oracle(exe, plonk, name, tmp_path):
         assert proof == PR.create_proof(opk, c.instances, c.advice, seed=17, transcript=tr, multiopen=mo), (name, fmt)
         assert PR.verify_proof(opk, c.instances, proof, transcript=tr, multiopen=mo)
         assert "commitments %d %d" % (c.cs.num_fixed, len(c.cs.permutation_columns)) in out
+        # WitnessStream (pinned staging, async upload, fence): same bytes as the resident path, seed by seed
+        streamed = [bytes.fromhex(ln.split()[1]) for ln in out.splitlines() if ln.startswith("streamed ")]
+        assert len(streamed) == 3 and streamed[0] == proof
+        if tr == "blake2b" and mo == "shplonk":
+            assert streamed[1] == PR.create_proof(opk, c.instances, c.advice, seed=18) and streamed[2] != streamed[1]
