@@ -61,6 +61,26 @@ int main() {
     }
     if (fails > 5) return 1;
   }
+  {  // sums of products with one reduction (f29_wide_*): sum_j a_j b_j, carried every six terms, against mul/add
+    for (int t = 0; t < 300; t++) {
+      const int m = 1 + (int)(rnd() % 40);
+      F29Wide w;
+      f29_wide_zero(w);
+      Fq want = Fq::zero();
+      for (int j = 0; j < m; j++) {
+        Fq x = rand_fq(), y = rand_fq();
+        Fq29 a = fq29_from_r256(x), b = fq29_from_r256(y);
+        a = fq29_unpack(fq29_pack_canonical(a));  // canonical operands (below p), as the kernels feed them
+        b = fq29_unpack(fq29_pack_canonical(b));
+        f29_wide_madd(w, a, b.l);
+        if (j % 6 == 5) f29_wide_carry(w);
+        want = add(want, mul(x, y));
+      }
+      f29_wide_carry(w);
+      Fq29 r = f29_reduce_weak(f29_wide_redc<Fq29P>(w));
+      if (!eq(fq29_to_r256(r), want)) { fails++; printf("wide sum of %d products\n", m); if (fails > 5) return 1; }
+    }
+  }
   printf("Fq29 field ok\n");
   // --- scalar field, mixed radix as ntt.hip uses it: data in radix 2^256 times a constant kept in radix 2^261
   for (int t = 0; t < 20000; t++) {
