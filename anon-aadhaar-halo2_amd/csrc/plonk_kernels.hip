@@ -448,29 +448,91 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(Fr* z, const Fr* totals
 }
 
 // ------------------------------------------------------------------------------ evaluation
-// out[q] = polys[q](points[q]); lane t sums coefficients t, t+256, ... by Horner in x^256.
-__global__ __launch_bounds__(256) void poly_eval_kernel(const Fr* const* polys, const Fr* points, Fr* out, uint32_t n) {
-  __shared__ Fr red[256];
+// out[q] = polys[q](points[q]), one workgroup per query. Lane t owns coefficients t, t + 256, t + 512, ...:
+//   p(x) = sum_t x^t * sum_j c[t + 256 j] * (x^256)^j.
+// The inner sums are sums of products with ONE reduction (fp29.cuh f29_wide_*): the powers (x^256)^j, j < 256, are
+// built once per workgroup in LDS (thread j raises x^256 to the j-th power), then every term is 81 multiply-adds
+// into 17 un-carried columns — 109 instructions per coefficient against 256 for a Horner step (product, carry-
+// normalised sum, unpack). Polynomials longer than 2^16 take an outer Horner step per 2^16 coefficients. x^t comes
+// from two 16-entry tables (x^a, (x^16)^b) instead of a 16-product exponentiation per lane. Powers are kept as limbs in
+// radix 2^261, coefficients enter in the ordinary form (mixed-radix product).
+constexpr uint32_t PE_T = 256;  // lanes = stride of a lane's coefficients = entries of the power table
+__device__ __forceinline__ Fr29 pe_pow(const Fr29& base, uint32_t e, int bits) {  // base^e, e < 2^bits; radix 2^261 in and out
+  Fr29 r = f29_one<Fr29P>();
+#pragma unroll 1
+  for (int b = bits - 1; b >= 0; b--) {
+    r = f29_sqr(r);
+    if ((e >> b) & 1) r = f29_mul(r, base);
+  }
+  return r;
+}
+__global__ __launch_bounds__(PE_T) void poly_eval_kernel(const Fr* const* polys, const Fr* points, Fr* out, uint32_t n) {
+  __shared__ uint32_t XP[PE_T][9];   // (x^256)^j
+  __shared__ uint32_t XA[16][9], XB[16][9];  // x^a, (x^16)^b
+  __shared__ Fr red[PE_T];
   const uint32_t q = blockIdx.x, t = threadIdx.x;
   const Fr* p = polys[q];
-  const Fr x = ld_fr(points + q);
-  Fr x256 = x;
+  const Fr29 x = f29_mul(fr29_unpack(ld_fr(points + q)), f29_k_in<Fr29P>());  // x * 2^261, below 2p
+  Fr29 x16 = x;
 #pragma unroll 1
-  for (int i = 0; i < 8; i++) x256 = sqr(x256);
+  for (int i = 0; i < 4; i++) x16 = f29_sqr(x16);
+  Fr29 x256 = x16;
+#pragma unroll 1
+  for (int i = 0; i < 4; i++) x256 = f29_sqr(x256);
+  const uint32_t J = (n + PE_T - 1) / PE_T;       // coefficients per lane (at most)
+  const uint32_t ts = J < PE_T ? J : PE_T;          // power-table entries in use
+  const uint32_t nseg = (J + PE_T - 1) / PE_T;
+  {
+    const Fr29 e = pe_pow(x256, t, 8);  // every lane: the loop is uniform, the products are masked
+    if (t < ts) {
+#pragma unroll
+      for (int i = 0; i < 9; i++) XP[t][i] = e.l[i];
+    }
+    if (t < 32) {
+      const Fr29 f = pe_pow(t < 16 ? x : x16, t & 15, 4);
+#pragma unroll
+      for (int i = 0; i < 9; i++) (t < 16 ? XA : XB)[t & 15][i] = f.l[i];
+    }
+  }
+  Fr29 xbig = x256;  // (x^256)^256, the step between segments
+  if (nseg > 1) {
+#pragma unroll 1
+    for (int i = 0; i < 8; i++) xbig = f29_sqr(xbig);
+  }
+  __syncthreads();
   Fr s = Fr::zero();
   if (t < n) {
-    uint32_t top = (n - 1 - t) / 256;  // largest j with t + 256 j < n
-    // Horner on limbs: the multiplier in radix 2^261 (mixed-radix product: data stays in the ordinary form), the
-    // running value lazily reduced — a product (< 2p) plus a canonical coefficient stays below 3p
-    const Fr29 x256r = fr29_unpack(fr29_const_to_r261(x256));
-    Fr29 acc = fr29_unpack(ld_fr(p + t + 256u * top));
-    for (uint32_t j = top; j-- > 0;) acc = f29_add(f29_mul(acc, x256r), fr29_unpack(ld_fr(p + t + 256u * j)));
+    Fr29 acc;
+#pragma unroll
+    for (int i = 0; i < 9; i++) acc.l[i] = 0;
+#pragma unroll 1
+    for (uint32_t seg = nseg; seg-- > 0;) {
+      F29Wide w;
+      f29_wide_zero(w);
+      const uint32_t j0 = seg * PE_T, jn = (J - j0) < PE_T ? (J - j0) : PE_T;
+#pragma unroll 1
+      for (uint32_t j = 0; j < jn; j++) {
+        const uint32_t idx = t + PE_T * (j0 + j);
+        if (idx < n) f29_wide_madd(w, fr29_unpack(ld_fr(p + idx)), XP[j]);
+        if (j % 6 == 5) f29_wide_carry(w);
+      }
+      f29_wide_carry(w);
+      const Fr29 part = f29_wide_redc<Fr29P>(w);  // below 256 * 2 / 169.3 + 1 < 4.1 p
+      // segments from the top down: acc = acc * (x^256)^256 + part; acc below 2 + 4.1
+      acc = seg + 1 == nseg ? part : f29_add(f29_mul(acc, xbig), part);
+    }
+    Fr29 xa, xb;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      xa.l[i] = XA[t & 15][i];
+      xb.l[i] = XB[t >> 4][i];
+    }
+    acc = f29_mul(f29_mul(acc, xa), xb);  // * x^t; 6.1 * 2 and 2 * 2 stay far inside the product's range
     s = f29_pack_canonical<FrP>(f29_reduce_weak(acc));
-    s = mul(s, pow_u64(x, t));
   }
   red[t] = s;
   __syncthreads();
-  for (uint32_t d = 128; d >= 1; d >>= 1) {
+  for (uint32_t d = PE_T / 2; d >= 1; d >>= 1) {
     if (t < d) red[t] = add(red[t], red[t + d]);
     __syncthreads();
   }
