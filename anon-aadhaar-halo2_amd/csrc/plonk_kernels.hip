@@ -39,12 +39,36 @@ __device__ __forceinline__ void st_fr(Fr* p, const Fr& v) {
 }
 
 // ------------------------------------------------------------------------------ interpreter
-// Two latency measures, both value-neutral: (1) in the quotient-domain interpreter the columns that almost every
-// constraint touches at rotation 0 (l_0, l_last, l_active and the coset point X) are loaded once per row into
-// registers ("hot" slots, ExprArgs::hot); (2) the column operand of the NEXT instruction is fetched while the
-// current one executes, so a global load is in flight behind every field multiplication.
+// Shape of both interpreters (what tools/isa_walk.py — a control-flow walk of the compiled kernel — says matters):
+//  * the instruction stream is read through the CONSTANT address space: wave-uniform 16-byte scalar loads straight into
+//    SGPRs, two instructions ahead, no vector load + wait + readfirstlane in front of every instruction;
+//  * the operand of the NEXT instruction (a column's row, or a constant every lane reads alike) is ALWAYS fetched
+//    while the current one executes — instructions without an operand name a dummy constant (prover.hip
+//    upload_program), and the program ends in two END instructions, so neither fetch is conditional;
+//  * hipcc structurizes the (uniform) dispatch, and every loop-carried register is then copied twice per interpreted
+//    instruction at the merge blocks: only the top of stack and the operand in flight are loop-carried registers.
 __device__ __forceinline__ bool op_reads_col(uint32_t op) {
   return op == OP_PUSH_COL || op == OP_MUL_COL || op == OP_ADD_COL || op == OP_SUB_COL;
+}
+typedef const ExprInstr __attribute__((address_space(4))) * ExprProgPtr;
+struct ExprWord {  // one instruction in scalar registers
+  uint32_t op_arg;
+  int32_t rot;
+  const Fr* ptr;
+};
+__device__ __forceinline__ ExprWord expr_word(ExprProgPtr prog, uint32_t i) {
+  ExprWord w;
+  w.op_arg = prog[i].op_arg;
+  w.rot = prog[i].rot;
+  w.ptr = prog[i].ptr;
+  return w;
+}
+// rows come in blocks of mask + 1 = n (one block in the Lagrange domain, one per coset in the quotient domain): a
+// rotation wraps inside the row's own block; operands that are not columns are read at index 0 by every lane
+__device__ __forceinline__ Fr expr_fetch(const ExprWord& in, size_t row, size_t blk_base, size_t mask) {
+  const size_t sel = op_reads_col(in.op_arg >> 24) ? ~(size_t)0 : 0;
+  const size_t idx = (blk_base + ((row + (size_t)(int64_t)in.rot) & mask)) & sel;
+  return ld_fr(in.ptr + idx);
 }
 
 // Lagrange-domain programs (lookup compression, the fractions of the grand products): columns, constants and results in
@@ -57,52 +81,33 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_kernel(ExprArgs a) {
   const size_t row = (size_t)blockIdx.x * EXPR_THREADS + tid;
   if (row >= a.nrows) return;  // domains smaller than one block (no barriers below, so an early exit is safe)
   Fr tos = Fr::zero();
-  Fr h = Fr::zero();
-  const Fr yv = a.y_ptr ? ld_fr(a.y_ptr) : Fr::zero();
   uint32_t sp = 0;  // elements on the stack, including tos
-  // Software pipeline over the (wave-uniform) instruction stream: while instruction pc executes, the
-  // operand of pc+1 is in flight (vector load) and instruction pc+2 is being fetched (scalar load).
-  const ExprInstr nop{0u, 0, nullptr};
-  // rows come in blocks of mask + 1 = n (one block in the Lagrange domain, one per coset in the quotient domain):
-  // a rotation wraps inside the row's own block
   const size_t blk_base = row & ~a.mask;
-  auto fetch = [&](const ExprInstr& in) -> Fr {
-    const size_t idx = blk_base + ((row + (size_t)(int64_t)in.rot) & a.mask);
-    return ld_fr(in.ptr + idx);
-  };
-  ExprInstr cur = a.prog_len > 0 ? a.prog[0] : nop;
-  ExprInstr nxt = a.prog_len > 1 ? a.prog[1] : nop;
-  Fr pre = op_reads_col(cur.op_arg >> 24) ? fetch(cur) : Fr::zero();
+  const ExprProgPtr prog = (ExprProgPtr)a.prog;
+  ExprWord cur = expr_word(prog, 0), nxt = expr_word(prog, 1);
+  Fr pre = expr_fetch(cur, row, blk_base, a.mask);
   for (uint32_t pc = 0; pc < a.prog_len; pc++) {
     const uint32_t op = cur.op_arg >> 24, arg = cur.op_arg & 0xffffffu;
     const Fr v = pre;  // operand of this instruction (if it has one), fetched one instruction ago
-    const ExprInstr nn = pc + 2 < a.prog_len ? a.prog[pc + 2] : nop;
-    if (op_reads_col(nxt.op_arg >> 24)) pre = fetch(nxt);
+    const ExprWord nn = expr_word(prog, pc + 2);
+    pre = expr_fetch(nxt, row, blk_base, a.mask);
     switch (op) {
       case OP_PUSH_COL:
+      case OP_PUSH_CONST:
         if (sp > 0) stack[(sp - 1) * EXPR_THREADS + tid] = tos;
         tos = v;
         sp++;
         break;
       case OP_MUL_COL:
+      case OP_MUL_CONST:
         tos = fmul(tos, v);
         break;
       case OP_ADD_COL:
+      case OP_ADD_CONST:
         tos = add(tos, v);
         break;
       case OP_SUB_COL:
         tos = sub(tos, v);
-        break;
-      case OP_PUSH_CONST:
-        if (sp > 0) stack[(sp - 1) * EXPR_THREADS + tid] = tos;
-        tos = ld_fr(cur.ptr);
-        sp++;
-        break;
-      case OP_MUL_CONST:
-        tos = fmul(tos, ld_fr(cur.ptr));
-        break;
-      case OP_ADD_CONST:
-        tos = add(tos, ld_fr(cur.ptr));
         break;
       case OP_ADD:
         tos = add(stack[(sp - 2) * EXPR_THREADS + tid], tos);
@@ -122,11 +127,6 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_kernel(ExprArgs a) {
       case OP_SQR:
         tos = fmul(tos, tos);
         break;
-      case OP_ACC:  // h = h*y + value
-        h = add(fmul(h, yv), tos);
-        sp--;
-        if (sp > 0) tos = stack[(sp - 1) * EXPR_THREADS + tid];
-        break;
       case OP_STORE:
         st_fr(a.outs[arg] + row, tos);
         sp--;
@@ -138,18 +138,22 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_kernel(ExprArgs a) {
     cur = nxt;
     nxt = nn;
   }
-  if (a.h_out) st_fr(a.h_out + row, h);
 }
 
 // ------------------------------------------------------------------------------ interpreter, limb-resident
 // The h(X) program (radix 2^261 data) spends most of its time in products whose operands and results used to be packed
 // to canonical 32-byte values and unpacked again around every operation (81 of 310 instructions per product). Here the
-// top of stack, the accumulator h, the hot columns and y live on 9 x 29-bit limbs (fp29.cuh), lazily reduced: sums
+// top of stack and the coset's X values live on 9 x 29-bit limbs (fp29.cuh), lazily reduced: sums
 // and differences are limb-wise with a carry pass, products reset the bound to 2p, and the host — which knows the
 // whole (wave-uniform) program — tracks every value's bound and inserts OP_REDUCE where a product or a difference
-// would leave its range (prover.hip finalize_limb_program). `h = h*y + tos*x`, the end of nearly every gate and
-// argument term, is one two-product reduction (f29_mul2). Columns and constants are unpacked when they are read;
-// the operand stack below the top is in LDS as limbs (36 B per entry). No per-thread arrays, so nothing in scratch.
+// would leave its range (prover.hip finalize_limb_program). The fold with y, h = sum_j y^(K-1-j) term_j, is a sum of
+// products with ONE reduction per group of terms (fp29.cuh f29_wide_*): the host groups the terms by the hot column
+// that multiplies them (l_0, l_last, l_active, or none), each term is added as term_j * y^(K-1-j) — 81 multiply-adds
+// into 17 un-carried columns, the power a per-proof constant — and a group is reduced, multiplied by its hot column
+// and added to h once: 4 reductions and 3 hot-column products per row instead of 332 and 239. The operand of every
+// instruction is unpacked at the top of the loop; the operand stack below the top is in LDS as limbs (36 B per
+// entry), and so are the 17 columns (8 B each); h is read-modified-written in its output row by the 4 flushes.
+// No per-thread arrays, so nothing in scratch.
 __device__ __forceinline__ Fr29 lds_ld29(const uint32_t* s, uint32_t slot, uint32_t tid) {
   Fr29 r;
 #pragma unroll
@@ -163,74 +167,64 @@ __device__ __forceinline__ void lds_st29(uint32_t* s, uint32_t slot, uint32_t ti
 
 __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_limbs_kernel(ExprArgs a) {
   extern __shared__ uint4 lds_raw[];
-  uint32_t* stack = reinterpret_cast<uint32_t*>(lds_raw);  // [depth][9][EXPR_THREADS]
+  // State that only a few instructions touch does not live in registers: hipcc structurizes the (wave-uniform)
+  // dispatch, and every loop-carried register is then copied twice per interpreted instruction at the merge blocks
+  // (tools/isa_walk.py: 34 + 18 of ~130 overhead instructions were `wide` and h). The 17 un-carried columns of the
+  // sum of products sit in LDS (one 64-bit slot per column and lane), h in its output row.
+  uint64_t* wide_lds = reinterpret_cast<uint64_t*>(lds_raw);                                  // [17][EXPR_THREADS]
+  uint32_t* stack = reinterpret_cast<uint32_t*>(wide_lds + (size_t)17 * EXPR_THREADS);        // [depth][9][EXPR_THREADS]
   const uint32_t tid = threadIdx.x;
   const size_t row = (size_t)blockIdx.x * EXPR_THREADS + tid;
   if (row >= a.nrows) return;  // no barriers below
-  Fr29 tos, h;
+  Fr29 tos;
 #pragma unroll
-  for (int i = 0; i < 9; i++) tos.l[i] = h.l[i] = 0;
-  // y and the hot columns as named values, selected limb by limb: an indexed array, or a `?:` between whole structs,
-  // makes hipcc keep them in scratch memory
-  Fr29 yv = tos, hot0 = tos, hot1 = tos, hot2 = tos, hot3 = tos;
-  if (a.y_ptr) yv = fr29_unpack(ld_fr(a.y_ptr));
-  if (a.hot[0] != EXPR_NO_SLOT) hot0 = fr29_unpack(ld_fr(a.cols[a.hot[0]] + row));
-  if (a.hot[1] != EXPR_NO_SLOT) hot1 = fr29_unpack(ld_fr(a.cols[a.hot[1]] + row));
-  if (a.hot[2] != EXPR_NO_SLOT) hot2 = fr29_unpack(ld_fr(a.cols[a.hot[2]] + row));
-  if (a.hot[3] != EXPR_NO_SLOT) hot3 = fr29_unpack(ld_fr(a.cols[a.hot[3]] + row));
+  for (int i = 0; i < 9; i++) tos.l[i] = 0;
+#pragma unroll
+  for (int k = 0; k < 17; k++) wide_lds[k * EXPR_THREADS + tid] = 0;
+  // hot[3] (the coset's X values: an operand of every permutation factor) stays in registers; hot[0..2] (l_0, l_last,
+  // l_active) multiply a whole group of terms once each and are read from memory when that happens — 27 registers
+  // that keep three waves per SIMD resident.
+  Fr29 hotx = tos;
+  if (a.hot[3] != EXPR_NO_SLOT) hotx = fr29_unpack(ld_fr(a.cols[a.hot[3]] + row));
+  auto hot = [&](uint32_t k) -> Fr29 { return fr29_unpack(ld_fr(a.cols[a.hot[k]] + row)); };
   uint32_t sp = 0;  // elements on the stack, including tos
-  const ExprInstr nop{0u, 0, nullptr};
   const size_t blk_base = row & ~a.mask;
-  auto fetch = [&](const ExprInstr& in) -> Fr {
-    const size_t idx = blk_base + ((row + (size_t)(int64_t)in.rot) & a.mask);
-    return ld_fr(in.ptr + idx);
-  };
-  auto reads_col = [](uint32_t op) { return op_reads_col(op) || op == OP_ACC_MUL_COL; };
-  ExprInstr cur = a.prog_len > 0 ? a.prog[0] : nop;
-  ExprInstr nxt = a.prog_len > 1 ? a.prog[1] : nop;
-  Fr pre = reads_col(cur.op_arg >> 24) ? fetch(cur) : Fr::zero();
+  const ExprProgPtr prog = (ExprProgPtr)a.prog;
+  ExprWord cur = expr_word(prog, 0), nxt = expr_word(prog, 1);
+  Fr pre = expr_fetch(cur, row, blk_base, a.mask);
   for (uint32_t pc = 0; pc < a.prog_len; pc++) {
     const uint32_t op = cur.op_arg >> 24, arg = cur.op_arg & 0xffffffu;
-    const Fr v = pre;
-    const ExprInstr nn = pc + 2 < a.prog_len ? a.prog[pc + 2] : nop;
-    if (reads_col(nxt.op_arg >> 24)) pre = fetch(nxt);
+    // the operand of this instruction (if it has one) as limbs: unpacking is also what frees `pre` for the next fetch
+    const Fr29 x = fr29_unpack(pre);
+    const ExprWord nn = expr_word(prog, pc + 2);
+    pre = expr_fetch(nxt, row, blk_base, a.mask);
     switch (op) {
       case OP_PUSH_COL:
+      case OP_PUSH_CONST:
         if (sp > 0) lds_st29(stack, sp - 1, tid, tos);
-        tos = fr29_unpack(v);
+        tos = x;
         sp++;
         break;
       case OP_MUL_COL:
-        tos = f29_mul(tos, fr29_unpack(v));
+      case OP_MUL_CONST:
+        tos = f29_mul(tos, x);
         break;
       case OP_ADD_COL:
-        tos = f29_add(tos, fr29_unpack(v));
+      case OP_ADD_CONST:
+        tos = f29_add(tos, x);
         break;
       case OP_SUB_COL:
-        tos = f29_sub3(tos, fr29_unpack(v));
+        tos = f29_sub3(tos, x);
         break;
       case OP_PUSH_HOT:
         if (sp > 0) lds_st29(stack, sp - 1, tid, tos);
-#pragma unroll
-        for (int i = 0; i < 9; i++) tos.l[i] = arg == 0 ? hot0.l[i] : arg == 1 ? hot1.l[i] : arg == 2 ? hot2.l[i] : hot3.l[i];
+        if (arg == 3) tos = hotx;
+        else tos = hot(arg);
         sp++;
         break;
       case OP_MUL_HOT:
-        if (arg == 0) tos = f29_mul(tos, hot0);
-        else if (arg == 1) tos = f29_mul(tos, hot1);
-        else if (arg == 2) tos = f29_mul(tos, hot2);
-        else tos = f29_mul(tos, hot3);
-        break;
-      case OP_PUSH_CONST:
-        if (sp > 0) lds_st29(stack, sp - 1, tid, tos);
-        tos = fr29_unpack(ld_fr(cur.ptr));
-        sp++;
-        break;
-      case OP_MUL_CONST:
-        tos = f29_mul(tos, fr29_unpack(ld_fr(cur.ptr)));
-        break;
-      case OP_ADD_CONST:
-        tos = f29_add(tos, fr29_unpack(ld_fr(cur.ptr)));
+        if (arg == 3) tos = f29_mul(tos, hotx);
+        else tos = f29_mul(tos, hot(arg));
         break;
       case OP_ADD:
         tos = f29_add(lds_ld29(stack, sp - 2, tid), tos);
@@ -260,34 +254,50 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_limbs_kernel(ExprArgs 
       case OP_REDUCE:
         tos = f29_reduce_weak(tos);
         break;
-      case OP_ACC:  // h = h*y + value
-        h = f29_add(f29_mul(h, yv), tos);
+      case OP_WACC: {  // wide += tos * y^(K-1-j), the power (radix 2^261, canonical) fetched like a constant
+        // column by column through LDS; a column takes six terms of 9 * 2^58 before its carries must move up: the
+        // host marks every sixth term of a group (bit 23) and the carry pass rides along with that term (two copies of
+        // the loop: as one loop with a flag, every term pays six selects per column)
+        if ((arg >> 23) & 1) {
+          uint64_t up = 0;
+#pragma unroll
+          for (int k = 0; k < 17; k++) {
+            uint64_t c = wide_lds[k * EXPR_THREADS + tid] + up;
+#pragma unroll
+            for (int i = (k > 8 ? k - 8 : 0); i <= (k < 8 ? k : 8); i++) f29_mad_vv(c, tos.l[i], x.l[k - i]);
+            if (k < 16) {
+              up = c >> 29;
+              c &= F29_MASK;
+            }
+            wide_lds[k * EXPR_THREADS + tid] = c;
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 17; k++) {
+            uint64_t c = wide_lds[k * EXPR_THREADS + tid];
+#pragma unroll
+            for (int i = (k > 8 ? k - 8 : 0); i <= (k < 8 ? k : 8); i++) f29_mad_vv(c, tos.l[i], x.l[k - i]);
+            wide_lds[k * EXPR_THREADS + tid] = c;
+          }
+        }
         sp--;
         if (sp > 0) tos = lds_ld29(stack, sp - 1, tid);
-        break;
-      case OP_ACC_MUL_COL:
-        h = f29_mul2(h, yv, tos, fr29_unpack(v));
-        sp--;
-        if (sp > 0) tos = lds_ld29(stack, sp - 1, tid);
-        break;
-      case OP_ACC_MUL_CONST:
-        h = f29_mul2(h, yv, tos, fr29_unpack(ld_fr(cur.ptr)));
-        sp--;
-        if (sp > 0) tos = lds_ld29(stack, sp - 1, tid);
-        break;
-      case OP_ACC_MUL_HOT:
-        if (arg == 0) h = f29_mul2(h, yv, tos, hot0);
-        else if (arg == 1) h = f29_mul2(h, yv, tos, hot1);
-        else if (arg == 2) h = f29_mul2(h, yv, tos, hot2);
-        else h = f29_mul2(h, yv, tos, hot3);
-        sp--;
-        if (sp > 0) tos = lds_ld29(stack, sp - 1, tid);
-        break;
-      case OP_ACC_MUL:
-        h = f29_mul2(h, yv, lds_ld29(stack, sp - 2, tid), tos);
-        sp -= 2;
-        if (sp > 0) tos = lds_ld29(stack, sp - 1, tid);
-        break;
+      } break;
+      case OP_WFLUSH: {  // h (+)= reduce(wide) * hot;  wide = 0. The group's sum is within the reduction's range (host)
+        F29Wide wide;
+#pragma unroll
+        for (int k = 0; k < 17; k++) {
+          wide.c[k] = wide_lds[k * EXPR_THREADS + tid];
+          wide_lds[k * EXPR_THREADS + tid] = 0;
+        }
+        f29_wide_carry(wide);
+        Fr29 g = f29_wide_redc<Fr29P>(wide);
+        const uint32_t k = arg & 7;
+        if (k == 3) g = f29_mul(g, hotx);
+        else if (k < 3) g = f29_mul(g, hot(k));
+        if (!(arg & 16)) g = f29_add(g, fr29_unpack(ld_fr(a.h_out + row)));  // bit 4: the first group of the program
+        st_fr(a.h_out + row, f29_pack_canonical<FrP>(f29_reduce_weak(g)));
+      } break;
       case OP_STORE:  // the host reduced tos below 2p
         st_fr(a.outs[arg] + row, f29_pack_canonical<FrP>(tos));
         sp--;
@@ -299,7 +309,6 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_limbs_kernel(ExprArgs 
     cur = nxt;
     nxt = nn;
   }
-  if (a.h_out) st_fr(a.h_out + row, f29_pack_canonical<FrP>(f29_reduce_weak(h)));
 }
 
 // ------------------------------------------------------------------------------ Fr::random on the device
@@ -807,7 +816,7 @@ int zk_expr_eval(amdzk_ctx* ctx, const ExprArgs& a, uint32_t depth, const char* 
 }
 
 int zk_expr_eval_limbs(amdzk_ctx* ctx, const ExprArgs& a, uint32_t depth, const char* name) {
-  size_t shmem = (size_t)(depth ? depth : 1) * EXPR_THREADS * 9 * sizeof(uint32_t);
+  size_t shmem = (size_t)(depth ? depth : 1) * EXPR_THREADS * 9 * sizeof(uint32_t) + (size_t)17 * EXPR_THREADS * sizeof(uint64_t);
   const dim3 grid((unsigned)((a.nrows + EXPR_THREADS - 1) / EXPR_THREADS)), block(EXPR_THREADS);
   if (shmem > 65536) ZK_HIP(ctx, hipFuncSetAttribute((const void*)expr_eval_limbs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   ZK_LAUNCH(ctx, name, expr_eval_limbs_kernel, grid, block, shmem, a);

@@ -18,7 +18,8 @@ enum ExprOp : uint32_t {
   OP_MUL_COL = 9,
   OP_ADD_COL = 10,
   OP_SUB_COL = 11,
-  OP_ACC = 12,    // h = h*y + pop()
+  OP_ACC = 12,    // h = h*y + pop(): host-side programs only (prover.hip finalize_limb_program turns the fold into
+                  // OP_WACC / OP_WFLUSH); neither interpreter executes it
   OP_STORE = 13,  // outs[arg][row] = pop()
   OP_SQR = 14,
   OP_PUSH_HOT = 15,  // push hot[arg]
@@ -28,10 +29,12 @@ enum ExprOp : uint32_t {
   OP_REDUCE = 17,       // tos = weak reduction of tos (below 1.0002 p)
   OP_SUB_BIG = 18,      // as OP_SUB with a subtrahend (tos) between 2p and 9p
   OP_NEG_BIG = 19,      // as OP_NEG with tos between 2p and 9p
-  OP_ACC_MUL_COL = 20,  // h = h*y + tos * column   (one Montgomery reduction for both products)
-  OP_ACC_MUL_CONST = 21,
-  OP_ACC_MUL_HOT = 22,
-  OP_ACC_MUL = 23,      // h = h*y + stack[sp-2] * tos
+  // h(X) = sum_j y^(K-1-j) term_j is not folded by Horner there: the terms are grouped by the hot column that
+  // multiplies them, every term is ADDED, UNREDUCED, into 17 un-carried columns as term_j * y^(K-1-j) (one constant
+  // per term, refreshed per proof), and a group is reduced once, multiplied by its hot column once and added to h
+  OP_WACC = 20,         // wide += pop() * y^(K-1-j), j = arg & 0x7fffff (ExprInstr::ptr: that power, radix 2^261);
+                        // arg bit 23: move the columns' carries up with this term (every sixth term of a group)
+  OP_WFLUSH = 21,       // h_out[row] (+)= reduce(wide) * hot[arg & 7]  (4: no factor);  wide = 0;  arg & 16: first group (=, not +=)
 };
 
 constexpr int EXPR_HOT = 4;
@@ -39,7 +42,8 @@ constexpr uint32_t EXPR_NO_SLOT = 0xffffffffu;
 
 // One resolved instruction (16 bytes, fetched with a single scalar load): op << 24 | arg, the row
 // offset of the operand's rotation (already scaled for the domain), and the operand's base address —
-// a column for *_COL ops, the constant itself for *_CONST ops.
+// a column for *_COL ops, the constant itself for *_CONST ops and OP_WACC, a dummy constant for every
+// other op (the interpreters fetch the operand unconditionally). A program ends in two OP_END words.
 struct ExprInstr {
   uint32_t op_arg;
   int32_t rot;
@@ -51,11 +55,11 @@ struct ExprArgs {
   uint32_t prog_len;
   const bn254::Fr* const* cols;  // slot -> column base (device array of device pointers); used for the hot slots
   bn254::Fr* const* outs;        // OP_STORE targets
-  bn254::Fr* h_out;              // OP_ACC result per row (may be null)
+  bn254::Fr* h_out;              // OP_WFLUSH: h per row, canonical (may be null for programs without it)
   size_t mask;                   // n - 1: rotations wrap inside blocks of n rows (nrows = n, or nc * n in the quotient domain)
   size_t nrows;
-  const bn254::Fr* y_ptr;        // y (OP_ACC)
-  uint32_t hot[EXPR_HOT];        // column slots held in registers for the whole row (rotation 0), or EXPR_NO_SLOT
+  uint32_t hot[EXPR_HOT];        // column slots the hot ops read at rotation 0, or EXPR_NO_SLOT (limb interpreter: slot 3 is
+                                 // held in registers for the whole row, 0..2 are read where a group is flushed)
   // 0: columns, constants and results are in halo2curves' radix-2^256 Montgomery form (bn254.cuh product).
   // 1: everything the program touches is in radix 2^261 (32 x the value in the ordinary form): products use
   //    fp29.cuh's in-place 29-bit product. The prover runs the h(X) program this way (extended domain only).

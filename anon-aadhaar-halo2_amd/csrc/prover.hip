@@ -162,6 +162,8 @@ struct amdzk_pk {
   RotTable rots;
   Fr* d_consts = nullptr;
   Fr* d_consts261 = nullptr;  // the same table times 32 (= radix 2^261): constants of programs run on the extended domain
+  uint32_t h_terms = 0;       // terms of the h(X) program = powers of y its OP_WACC ops index
+  Fr* d_ypow = nullptr;       // [h_terms]: y^(h_terms-1-j) in radix 2^261, refreshed per proof
   const Fr** d_cols_lag = nullptr;
   const Fr** d_cols_ext = nullptr;
   Fr** d_outs_compress = nullptr;
@@ -444,26 +446,34 @@ int emit_compressed(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, uint32_t first, u
 //     for the K*p constants (below 2p: K = 3, below 9p: K = 10), before a value sinks into the LDS stack with a bound
 //     above 8, and before OP_STORE (packing needs a value below 2p);
 //   * picks OP_SUB / OP_SUB_BIG and OP_NEG / OP_NEG_BIG by the subtrahend's bound;
-//   * fuses `tos = tos * x; h = h*y + tos` into one two-product reduction (OP_ACC_MUL_*).
+//   * replaces the Horner fold h = h*y + term (OP_ACC) by a sum of products with one reduction per group: the program
+//     is cut into its terms (the stack is empty at every OP_ACC), a term that ends in `* hot[k]` loses that factor
+//     and joins group k, the others group 4; term j of the original order adds term_j * y^(K-1-j) to the wide
+//     accumulator (OP_WACC j; every sixth term of a group also moves the columns' carries up), and each group ends
+//     with OP_WFLUSH k: h (+)= reduce(wide) * hot[k], h canonical in its output row. A group is split when its sum of
+//     bounds would leave the reduction's range.
 // Bounds: a column, constant or hot value is below 1 (canonical); a product is below 2; a sum adds the bounds; a
-// difference a - b adds K to a's; the weak reduction gives 1.0002.
-void finalize_limb_program(Program& pr) {
+// difference a - b adds K to a's; the weak reduction gives 1.0002; a flushed group sum(bounds) / 169.3 + 1.
+// Returns the number of terms (= y powers the kernel needs, ExprArgs::ypow).
+uint32_t finalize_limb_program(Program& pr) {
+  const double LIM = 160.0, RED = 1.01, GROUP_LIM = 169.0 * 30.0;  // a flushed group stays below ~31 p (+ h, canonical)
+  struct Term {
+    std::vector<uint32_t> words;
+    double bound = 0;
+    uint32_t index = 0, group = 4;
+  };
+  std::vector<Term> terms;
+  std::vector<uint32_t> tail;  // programs without OP_ACC (OP_STORE only) keep their order
   std::vector<uint32_t> out;
   std::vector<double> st;  // bounds, st.back() = top of stack
-  double hb = 0.0;         // bound of the accumulator h
-  const double LIM = 160.0, RED = 1.01;
-  size_t last_mul = (size_t)-1;  // index in `out` of a product that made the current top of stack, if it is the last op
-  double mul_a = 0, mul_b = 0;   // its operands' bounds
   auto emit = [&](uint32_t op, uint32_t arg = 0) { out.push_back((op << 24) | (arg & 0xffffffu)); };
   auto reduce_tos = [&]() {
     emit(OP_REDUCE);
     st.back() = RED;
   };
-  uint32_t depth = 0;
-  for (uint32_t w : pr.words) {
-    const uint32_t op = w >> 24, arg = w & 0xffffffu;
-    const bool was_mul = last_mul == out.size() - 1 && !out.empty();
-    size_t this_mul = (size_t)-1;
+  uint32_t depth = 0, nterms = 0;
+  for (size_t wi = 0; wi < pr.words.size(); wi++) {
+    const uint32_t w = pr.words[wi], op = w >> 24, arg = w & 0xffffffu;
     switch (op) {
       case OP_PUSH_COL:
       case OP_PUSH_CONST:
@@ -472,14 +482,24 @@ void finalize_limb_program(Program& pr) {
         emit(op, arg);
         st.push_back(1.0);
         break;
+      case OP_MUL_HOT:
+        // the closing `* hot[k]` of a term is factored out of its group instead of being multiplied in
+        if (st.size() == 1 && wi + 1 < pr.words.size() && (pr.words[wi + 1] >> 24) == OP_ACC) {
+          Term t;
+          t.group = arg;
+          t.bound = st.back();
+          t.index = nterms++;
+          t.words.swap(out);
+          terms.push_back(std::move(t));
+          st.clear();
+          wi++;  // the OP_ACC is consumed
+          break;
+        }
+        [[fallthrough]];
       case OP_MUL_COL:
       case OP_MUL_CONST:
-      case OP_MUL_HOT:
         if (st.back() >= LIM) reduce_tos();
-        mul_a = st.back();
-        mul_b = 1.0;
         emit(op, arg);
-        this_mul = out.size() - 1;
         st.back() = 2.0;
         break;
       case OP_ADD_COL:
@@ -509,11 +529,8 @@ void finalize_limb_program(Program& pr) {
       } break;
       case OP_MUL: {
         if (st[st.size() - 2] * st.back() >= LIM) reduce_tos();
-        mul_b = st.back();
         st.pop_back();
-        mul_a = st.back();
         emit(op);
-        this_mul = out.size() - 1;
         st.back() = 2.0;
       } break;
       case OP_NEG:
@@ -526,35 +543,59 @@ void finalize_limb_program(Program& pr) {
         emit(op);
         st.back() = 2.0;
         break;
-      case OP_ACC:
-        if (was_mul && hb + mul_a * mul_b < LIM) {  // h*y + a*b in one reduction
-          const uint32_t mw = out.back();
-          out.pop_back();
-          const uint32_t mop = mw >> 24;
-          emit(mop == OP_MUL_COL ? OP_ACC_MUL_COL : mop == OP_MUL_CONST ? OP_ACC_MUL_CONST : mop == OP_MUL_HOT ? OP_ACC_MUL_HOT : OP_ACC_MUL,
-               mw & 0xffffffu);
-          hb = 2.0;
-        } else {
-          if (2.0 + st.back() > 40.0) reduce_tos();
-          emit(op);
-          hb = 2.0 + st.back();
-        }
-        st.pop_back();
-        break;
+      case OP_ACC: {  // end of a term without a hot factor
+        Term t;
+        t.group = 4;
+        t.bound = st.back();
+        t.index = nterms++;
+        t.words.swap(out);
+        terms.push_back(std::move(t));
+        st.clear();
+      } break;
       case OP_STORE:
         if (st.back() >= 2.0) reduce_tos();
         emit(op, arg);
         st.pop_back();
+        tail.insert(tail.end(), out.begin(), out.end());
+        out.clear();
         break;
       default:
         emit(op, arg);
         break;
     }
-    last_mul = this_mul;
     if (st.size() > depth) depth = (uint32_t)st.size();
   }
-  pr.words.swap(out);
-  pr.depth = depth + 1;  // OP_ACC_MUL reads two entries below the former product: keep one spare slot
+  tail.insert(tail.end(), out.begin(), out.end());
+  std::vector<uint32_t> fin;
+  bool first = true;
+  auto flush = [&](uint32_t g) {
+    fin.push_back((OP_WFLUSH << 24) | g | (first ? 16u : 0u));
+    first = false;
+  };
+  for (uint32_t g = 0; g <= 4; g++) {
+    double sum = 0;
+    uint32_t since_carry = 0;
+    bool open = false;
+    for (const Term& t : terms) {
+      if (t.group != g) continue;
+      if (open && sum + t.bound > GROUP_LIM) {
+        flush(g);
+        sum = 0;
+        since_carry = 0;
+      }
+      fin.insert(fin.end(), t.words.begin(), t.words.end());
+      const bool carry = ++since_carry == 6;  // a column holds six un-carried terms
+      if (carry) since_carry = 0;
+      fin.push_back((OP_WACC << 24) | (carry ? 1u << 23 : 0u) | t.index);
+      sum += t.bound;
+      open = true;
+    }
+    if (open) flush(g);
+  }
+  fin.insert(fin.end(), tail.begin(), tail.end());
+  pr.words.swap(fin);
+  pr.depth = depth + 1;
+  return nterms;
 }
 
 // d_consts261[i] = 32 * consts[i] in the ordinary form, i.e. consts[i] in radix 2^261 (a few hundred values).
@@ -569,23 +610,48 @@ int upload_consts261(amdzk_ctx* ctx, amdzk_pk* pk) {
   return AMDZK_OK;
 }
 
+// d_ypow[j] = y^(K-1-j) for the K terms of the h(X) program, radix 2^261 (upstream folds the constraint values with
+// Horner, h = h*y + value, in the same order: term j carries y^(K-1-j)).
+int upload_ypow(amdzk_ctx* ctx, amdzk_pk* pk) {
+  const uint32_t K = pk->h_terms;
+  if (!K) return AMDZK_OK;
+  Fr k32 = Fr::one();
+  for (int i = 0; i < 5; i++) k32 = add(k32, k32);
+  std::vector<Fr> pw(K);
+  Fr cur = k32;
+  const Fr y = pk->consts[pk->c_y];
+  for (uint32_t j = K; j-- > 0;) {
+    pw[j] = cur;
+    cur = mul(cur, y);
+  }
+  ZK_TRY(h2d_staged(ctx, pk, pk->d_ypow, pw.data(), pw.size() * 32));
+  if (!pk->pin || pw.size() * 32 > pk->pin_cap) ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return AMDZK_OK;
+}
+
 // Resolve slots / rotation indices / constant indices into addresses and row offsets for one domain
 // and upload the 16-byte instructions.
 int upload_program(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, bool extended) {
   const std::vector<const Fr*>& cols = extended ? pk->h_cols_ext : pk->h_cols_lag;
-  std::vector<ExprInstr> ins(pr.words.size());
-  for (size_t i = 0; i < pr.words.size(); i++) {
-    const uint32_t w = pr.words[i], op = w >> 24, arg = w & 0xffffffu;
+  // The interpreters fetch every instruction's operand, and the instruction two ahead, unconditionally: an
+  // instruction without an operand names the first constant, and two END instructions close the program.
+  const Fr* dummy = extended ? pk->d_consts261 : pk->d_consts;
+  std::vector<ExprInstr> ins(pr.words.size() + 2);
+  for (size_t i = 0; i < ins.size(); i++) {
+    const uint32_t w = i < pr.words.size() ? pr.words[i] : (uint32_t)OP_END << 24, op = w >> 24, arg = w & 0xffffffu;
     ins[i].op_arg = w;
     ins[i].rot = 0;
-    ins[i].ptr = nullptr;
-    if (op == OP_PUSH_COL || op == OP_MUL_COL || op == OP_ADD_COL || op == OP_SUB_COL || op == OP_ACC_MUL_COL) {
+    ins[i].ptr = dummy;
+    if (op == OP_PUSH_COL || op == OP_MUL_COL || op == OP_ADD_COL || op == OP_SUB_COL) {
       if ((arg >> 8) >= cols.size() || (arg & 0xff) >= pk->rots.rots.size()) ZK_FAIL(ctx, AMDZK_E_INVALID, "program: bad column operand");
       ins[i].ptr = cols[arg >> 8];
       ins[i].rot = pk->rots.rots[arg & 0xff];  // rows of one coset are consecutive: a rotation is a row offset in both domains
-    } else if (op == OP_PUSH_CONST || op == OP_MUL_CONST || op == OP_ADD_CONST || op == OP_ACC_MUL_CONST) {
+    } else if (op == OP_PUSH_CONST || op == OP_MUL_CONST || op == OP_ADD_CONST) {
       if (arg >= pk->consts.size()) ZK_FAIL(ctx, AMDZK_E_INVALID, "program: bad constant operand");
       ins[i].ptr = (extended ? pk->d_consts261 : pk->d_consts) + arg;
+    } else if (op == OP_WACC) {
+      if (!extended || (arg & 0x7fffffu) >= pk->h_terms) ZK_FAIL(ctx, AMDZK_E_INVALID, "program: bad power of y");
+      ins[i].ptr = pk->d_ypow + (arg & 0x7fffffu);
     }
   }
   ZK_TRY(dalloc(ctx, pk, &pr.d_instr, ins.size()));
@@ -607,7 +673,6 @@ int run_program(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, bool extended, Fr* co
   // zk_coeff_to_cosets_r261, their constants from d_consts261, and the result goes back through
   // zk_cosets_to_pieces. Lagrange-domain programs read the caller's radix-2^256 witness as is.
   a.radix261 = extended ? 1u : 0u;
-  a.y_ptr = (extended ? pk->d_consts261 : pk->d_consts) + pk->c_y;
   for (int i = 0; i < EXPR_HOT; i++) a.hot[i] = EXPR_NO_SLOT;
   if (extended && pr.uses_hot) {
     a.hot[0] = pk->se_l0();
@@ -672,6 +737,7 @@ void trace_pt(const char* label, const G1Affine& p) {
 static int quotient_pieces(amdzk_ctx* ctx, amdzk_pk* pk) {
   ZK_TRY(zk_coeff_to_cosets_r261(ctx, pk->dom, pk->P, pk->n, pk->PC, pk->ext, pk->NP));
   ZK_TRY(upload_consts261(ctx, pk));
+  ZK_TRY(upload_ypow(ctx, pk));
   ZK_TRY(run_program(ctx, pk, pk->prog_h, true, nullptr, pk->hq, "expr_evaluate_h"));
   ZK_TRY(zk_cosets_to_pieces(ctx, pk->dom, pk->hq, pk->hpieces, pk->qdeg));
   return AMDZK_OK;
@@ -1137,7 +1203,8 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
   KG_TRY(upload_program(ctx, pk, pk->prog_compress, false));
   KG_TRY(upload_program(ctx, pk, pk->prog_pfrac, false));
   KG_TRY(upload_program(ctx, pk, pk->prog_lfrac, false));
-  finalize_limb_program(pk->prog_h);
+  pk->h_terms = finalize_limb_program(pk->prog_h);
+  KG_TRY(dalloc(ctx, pk, &pk->d_ypow, (size_t)std::max<uint32_t>(pk->h_terms, 1)));
   KG_TRY(upload_program(ctx, pk, pk->prog_h, true));
   if (getenv("AMDZK_DUMP_PROG")) {  // debugging aid: what the compiled h(X) program is made of
     static const char* names[] = {"END", "PUSH_COL", "PUSH_CONST", "ADD", "SUB", "MUL", "NEG", "MUL_CONST", "ADD_CONST", "MUL_COL",
@@ -1169,7 +1236,7 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
     pr.op(OP_SUB_COL, COL(pk->se_llast(), r0));
     pr.op(OP_SUB_COL, COL(pk->se_lactive(), r0));
     pr.op(OP_STORE, 0); pr.pop();
-    finalize_limb_program(pr);
+    (void)finalize_limb_program(pr);
     KG_TRY(upload_program(ctx, pk, pr, true));
     Fr** d_out = nullptr;
     KG_TRY(dalloc(ctx, pk, &d_out, 1));
@@ -1859,7 +1926,7 @@ int amdzk_debug_limb_program(const uint32_t* words, size_t n, uint32_t* out, siz
   if ((!words && n) || !out_n) return AMDZK_E_INVALID;
   Program pr;
   pr.words.assign(words, words + n);
-  finalize_limb_program(pr);
+  (void)finalize_limb_program(pr);
   *out_n = pr.words.size();
   if (depth) *depth = pr.depth;
   if (out) {

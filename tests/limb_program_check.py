@@ -4,8 +4,7 @@ documents for each function, and asserts every precondition — the safety net b
 (prover.hip finalize_limb_program) that places the weak reductions."""
 
 OPS = dict(END=0, PUSH_COL=1, PUSH_CONST=2, ADD=3, SUB=4, MUL=5, NEG=6, MUL_CONST=7, ADD_CONST=8, MUL_COL=9, ADD_COL=10, SUB_COL=11, ACC=12,
-           STORE=13, SQR=14, PUSH_HOT=15, MUL_HOT=16, REDUCE=17, SUB_BIG=18, NEG_BIG=19, ACC_MUL_COL=20, ACC_MUL_CONST=21, ACC_MUL_HOT=22,
-           ACC_MUL=23)
+           STORE=13, SQR=14, PUSH_HOT=15, MUL_HOT=16, REDUCE=17, SUB_BIG=18, NEG_BIG=19, WACC=20, WFLUSH=21)
 NAME = {v: k for k, v in OPS.items()}
 MUL_RANGE = 169.0      # f29_mul / f29_sqr / f29_mul2: a*b (+ c*d) < 169 p^2
 VALUE_RANGE = 169.0    # a normalised value must stay below 2^261 = 169.3 p
@@ -16,8 +15,11 @@ def word(op, arg=0):
 
 
 def check(words):
-    """Returns (max stack depth, number of reductions, number of fused accumulates). Raises AssertionError."""
-    st, h, depth, nred, nfused = [], 0.0, 0, 0, 0
+    """Returns (max stack depth, number of reductions, number of terms added to the wide accumulator). Raises
+    AssertionError. Every power of y a WACC names must be used exactly once (a term dropped or doubled by the grouping
+    would go unnoticed by a bound walk alone)."""
+    st, depth, nred, nfused = [], 0, 0, 0
+    wide, seen, uncarried, flushes = 0.0, set(), 0, 0
     for pc, w in enumerate(words):
         op = NAME.get(w >> 24)
         where = "pc %d %s" % (pc, op)
@@ -52,27 +54,36 @@ def check(words):
             assert st[-1] < VALUE_RANGE, where
             st[-1] = 1.0002
             nred += 1
-        elif op == "ACC":                                    # h = h*y + t
-            assert h * 1.0 < MUL_RANGE, where
-            h = 2.0 + st.pop()
-        elif op in ("ACC_MUL_COL", "ACC_MUL_CONST", "ACC_MUL_HOT"):
-            assert h * 1.0 + st[-1] * 1.0 < MUL_RANGE, where  # f29_mul2(h, y, t, x)
-            st.pop()
-            h = 2.0
+        elif op == "ACC":                                    # Horner fold: not an instruction of finalised programs
+            raise AssertionError("ACC left in a finalised program at pc %d" % pc)
+        elif op == "WACC":                                   # wide += t * y^e: 81 multiply-adds, operands normalised
+            j = w & 0x7FFFFF
+            assert j not in seen, where + ": power %d used twice" % j
+            seen.add(j)
+            wide += st.pop() * 1.0                           # in units of p^2 (the power is canonical)
+            uncarried = 0 if w & (1 << 23) else uncarried + 1  # bit 23: the carries move up with this term
+            assert uncarried < 6, where + ": a column holds six terms of 9 * 2^58 at most"
             nfused += 1
-        elif op == "ACC_MUL":
-            b = st.pop()
-            a = st.pop()
-            assert h * 1.0 + a * b < MUL_RANGE, where
-            h = 2.0
-            nfused += 1
+        elif op == "WFLUSH":                                 # g = redc(wide) [* hot]; h = (h +) g, stored canonical
+            k = w & 7
+            assert k <= 4 and (w & 0xFFFFFF) & ~0x17 == 0, where
+            assert bool(w & 16) == (flushes == 0), where + ": exactly the first flush overwrites h"
+            flushes += 1
+            g = wide / 169.3 + 1.0                           # f29_wide_redc: T / 2^261 + p
+            assert g < VALUE_RANGE, where
+            if k < 4:
+                assert g * 1.0 < MUL_RANGE, where
+                g = 2.0
+            assert g + 1.0 < VALUE_RANGE, where              # + h (canonical), then f29_reduce_weak
+            wide, uncarried = 0.0, 0
         elif op == "STORE":                                  # f29_pack_canonical: below 2p
             assert st.pop() < 2.0, where
         elif op == "END":
             pass
         for v in st:
             assert v < VALUE_RANGE, where
-        assert h < VALUE_RANGE, where
         depth = max(depth, len(st))
     assert not st, "values left on the stack"
+    assert wide == 0.0, "terms left in the wide accumulator"
+    assert seen == set(range(len(seen))), "the powers of y are not 0..K-1"
     return depth, nred, nfused

@@ -26,13 +26,58 @@ def ops(words):
     return [LC.NAME[w >> 24] for w in words]
 
 
-def test_gate_shape_fuses_the_accumulate(pkg):
-    # q * (a + b*c - d), then h = h*y + that: the closing product joins the accumulate
+def test_gate_term_goes_to_the_wide_accumulator(pkg):
+    # q * (a + b*c - d), then h = h*y + that: the term is added as term * y^0, the group flushed without a factor
     prog = [W("PUSH_COL", 1), W("MUL_COL", 2), W("ADD_COL", 3), W("SUB_COL", 4), W("MUL_COL", 5), W("ACC")]
     out, depth = finalize(pkg, prog)
-    assert ops(out) == ["PUSH_COL", "MUL_COL", "ADD_COL", "SUB_COL", "ACC_MUL_COL"]
-    assert out[-1] & 0xFFFFFF == 5  # the operand of the fused product is kept
+    assert ops(out) == ["PUSH_COL", "MUL_COL", "ADD_COL", "SUB_COL", "MUL_COL", "WACC", "WFLUSH"]
+    assert out[-2] & 0xFFFFFF == 0 and out[-1] & 0xFFFFFF == 4 | 16  # power 0; no factor, first (and only) flush
     assert LC.check(out) == (1, 0, 1) and depth >= 1
+
+
+def test_terms_are_grouped_by_their_hot_factor_and_keep_their_power(pkg):
+    # five terms: plain, *hot0, *hot2, *hot0, plain -> groups hot0 {1, 3}, hot2 {2}, plain {0, 4}; the factor is dropped
+    # from the term and applied once per group
+    t = lambda col, hot=None: [W("PUSH_COL", col), W("SUB_COL", col + 1)] + ([W("MUL_HOT", hot)] if hot is not None else []) + [W("ACC")]
+    out, _ = finalize(pkg, t(0) + t(10, 0) + t(20, 2) + t(30, 0) + t(40))
+    o = ops(out)
+    assert "MUL_HOT" not in o and o.count("WACC") == 5 and o.count("WFLUSH") == 3
+    seq = [(LC.NAME[w >> 24], w & 0xFFFFFF) for w in out if LC.NAME[w >> 24] in ("PUSH_COL", "WACC", "WFLUSH")]
+    assert seq == [("PUSH_COL", 10), ("WACC", 1), ("PUSH_COL", 30), ("WACC", 3), ("WFLUSH", 0 | 16),
+                   ("PUSH_COL", 20), ("WACC", 2), ("WFLUSH", 2),
+                   ("PUSH_COL", 0), ("WACC", 0), ("PUSH_COL", 40), ("WACC", 4), ("WFLUSH", 4)]
+    assert LC.check(out) == (1, 0, 5)
+
+
+def test_a_hot_factor_inside_a_term_stays_a_product(pkg):
+    # hot * x + c is not `term * hot`: the product must stay in the term
+    prog = [W("PUSH_COL", 0), W("MUL_HOT", 1), W("ADD_COL", 2), W("ACC")]
+    out, _ = finalize(pkg, prog)
+    assert ops(out) == ["PUSH_COL", "MUL_HOT", "ADD_COL", "WACC", "WFLUSH"] and out[-1] & 7 == 4
+    LC.check(out)
+
+
+def test_a_large_group_is_split_and_carries_move_every_sixth_term(pkg):
+    # 1500 plain terms of bound ~38: the group is flushed every ~130 terms so the reduced sum stays small (h is kept
+    # canonical in its output row between flushes); every sixth term of a group carries
+    term = lambda i: [W("PUSH_COL", i)] + [W("ADD_COL", 1)] * 37 + [W("ACC")]
+    prog = []
+    for i in range(1500):
+        prog += term(i)
+    out, _ = finalize(pkg, prog)
+    flushes = [w & 0xFFFFFF for w in out if LC.NAME[w >> 24] == "WFLUSH"]
+    assert len(flushes) >= 10 and all(f & 7 == 4 for f in flushes) and [bool(f & 16) for f in flushes] == [True] + [False] * (len(flushes) - 1)
+    since, carries = 0, 0
+    for w in out:
+        if LC.NAME[w >> 24] == "WACC":
+            since += 1
+            if w & (1 << 23):
+                assert since == 6
+                since, carries = 0, carries + 1
+        elif LC.NAME[w >> 24] == "WFLUSH":
+            since = 0
+    assert carries >= 1500 // 6 - len(flushes)
+    assert LC.check(out)[2] == 1500
 
 
 def test_long_sum_is_reduced_before_it_leaves_range(pkg):
@@ -69,17 +114,17 @@ def test_values_sinking_into_the_stack_are_kept_small(pkg):
     prog = [W("PUSH_COL", 0)] + [W("ADD_COL", 1)] * 12 + [W("PUSH_COL", 2)] + [W("ADD_COL", 3)] * 12 + [W("MUL"), W("ACC")]
     out, depth = finalize(pkg, prog)
     o = ops(out)
-    assert o.count("REDUCE") >= 1 and o[-1] == "ACC_MUL"
+    assert o.count("REDUCE") >= 1 and o[-3:] == ["MUL", "WACC", "WFLUSH"]
     assert LC.check(out)[0] == 2 and depth >= 2
 
 
-def test_squares_and_unfusable_accumulates(pkg):
+def test_squares_and_hot_terms(pkg):
     prog = [W("PUSH_COL", 0)] + [W("ADD_COL", 1)] * 13 + [W("SQR"), W("SUB_COL", 0), W("MUL_HOT", 1), W("ACC"),
                                                         W("PUSH_COL", 3), W("ACC")]
     out, _ = finalize(pkg, prog)
     o = ops(out)
     assert o.index("REDUCE") < o.index("SQR")       # 14^2 > 169
-    assert "ACC_MUL_HOT" in o and o[-1] == "ACC"    # the second accumulate has no product in front of it
+    assert "MUL_HOT" not in o and o.count("WFLUSH") == 2   # group hot1 {0}, then the plain term
     LC.check(out)
 
 

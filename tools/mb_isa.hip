@@ -9,6 +9,7 @@ __global__ void k(uint64_t* out, int iters) {
   uint32_t x = threadIdx.x * 2654435761u + 12345u, y = x ^ 0x9e3779b9u;
   uint64_t a0 = x, a1 = y, a2 = x + 7, a3 = y + 9;
   uint32_t c0 = x, c1 = y, c2 = x + 3, c3 = y + 5;
+  uint64_t b0 = x + 11, b1 = y + 13;
   for (int i = 0; i < iters; i++) {
 #pragma unroll
     for (int u = 0; u < 16; u++) {
@@ -25,21 +26,34 @@ __global__ void k(uint64_t* out, int iters) {
                      : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : : "vcc");
       } else if (MODE == 4) {
         asm volatile("v_mul_lo_u32 %0, %0, %1\n\tv_mul_lo_u32 %1, %1, %2\n\tv_mul_lo_u32 %2, %2, %3\n\tv_mul_lo_u32 %3, %3, %0" : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
+      } else if (MODE == 6) {  // 4 mads + 4 moves, interleaved: do the cheap instructions issue in the multiplier's shadow?
+        asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_mov_b32 %4, %5\n\tv_mad_u64_u32 %1, vcc, %8, %9, %1\n\tv_mov_b32 %5, %6\n\t"
+                     "v_mad_u64_u32 %2, vcc, %8, %9, %2\n\tv_mov_b32 %6, %7\n\tv_mad_u64_u32 %3, vcc, %8, %9, %3\n\tv_mov_b32 %7, %4"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(x), "v"(y) : "vcc");
+      } else if (MODE == 7) {  // 4 mads + 4 and/shift (the limb-splitting instructions around a product)
+        asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_and_b32 %4, 0x1fffffff, %5\n\tv_mad_u64_u32 %1, vcc, %8, %9, %1\n\tv_lshrrev_b32 %5, 29, %6\n\t"
+                     "v_mad_u64_u32 %2, vcc, %8, %9, %2\n\tv_and_b32 %6, 0x1fffffff, %7\n\tv_mad_u64_u32 %3, vcc, %8, %9, %3\n\tv_lshrrev_b32 %7, 29, %4"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(x), "v"(y) : "vcc");
+      } else if (MODE == 8) {  // 4 mads + 4 LDS-free 64-bit adds
+        asm volatile("v_mad_u64_u32 %0, vcc, %6, %7, %0\n\tv_lshl_add_u64 %4, %4, 0, %5\n\tv_mad_u64_u32 %1, vcc, %6, %7, %1\n\tv_lshl_add_u64 %5, %5, 0, %4\n\t"
+                     "v_mad_u64_u32 %2, vcc, %6, %7, %2\n\tv_lshl_add_u64 %4, %4, 0, %5\n\tv_mad_u64_u32 %3, vcc, %6, %7, %3\n\tv_lshl_add_u64 %5, %5, 0, %4"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1) : "v"(x), "v"(y) : "vcc");
       } else if (MODE == 5) {  // mad with carry-out consumed by addc (the column-accumulate pattern)
         asm volatile("v_mad_u64_u32 %0, vcc, %4, %5, %0\n\tv_addc_co_u32 %2, vcc, 0, %2, vcc\n\tv_mad_u64_u32 %1, vcc, %4, %5, %1\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc"
                      : "+v"(a0), "+v"(a1), "+v"(c0), "+v"(c1) : "v"(x), "v"(y) : "vcc");
       }
     }
   }
-  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ c0 ^ c1 ^ c2 ^ c3;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ c0 ^ c1 ^ c2 ^ c3 ^ b0 ^ b1;
 }
 
 int main() {
   hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
   int cus = p.multiProcessorCount;
   void* buf; CK(hipMalloc(&buf, (size_t)cus * 8 * 256 * 8));
-  const char* names[6] = {"v_mad_u64_u32", "v_lshl_add_u64", "v_mov_b32", "v_add_co/addc_u32", "v_mul_lo_u32", "mad+addc pair (2 instr)"};
-  for (int mode = 0; mode < 6; mode++)
+  const char* names[9] = {"v_mad_u64_u32", "v_lshl_add_u64", "v_mov_b32", "v_add_co/addc_u32", "v_mul_lo_u32", "mad+addc pair (2 instr)",
+                          "4 mad + 4 v_mov (8 instr)", "4 mad + 4 and/shift (8 instr)", "4 mad + 4 v_lshl_add_u64 (8 instr)"};
+  for (int mode = 0; mode < 9; mode++)
     for (int wps = 1; wps <= 8; wps *= 2) {
       int blocks = cus * wps, iters = 1000;
       hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -51,12 +65,15 @@ int main() {
           case 3: k<3><<<blocks, 256>>>((uint64_t*)buf, iters); break;
           case 4: k<4><<<blocks, 256>>>((uint64_t*)buf, iters); break;
           case 5: k<5><<<blocks, 256>>>((uint64_t*)buf, iters); break;
+          case 6: k<6><<<blocks, 256>>>((uint64_t*)buf, iters); break;
+          case 7: k<7><<<blocks, 256>>>((uint64_t*)buf, iters); break;
+          case 8: k<8><<<blocks, 256>>>((uint64_t*)buf, iters); break;
         }
       };
       L(); CK(hipDeviceSynchronize());
       CK(hipEventRecord(a)); L(); L(); L(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
       float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 3;
-      double instrs = (double)blocks * 256 * iters * 64;  // 16 x 4 instructions per lane
+      double instrs = (double)blocks * 256 * iters * (mode >= 6 ? 128 : 64);  // 16 x 4 (or 8) instructions per lane
       double per_cu_clk = instrs / (ms * 1e-3) / cus / (p.clockRate * 1e3);
       printf("{\"instr\": \"%s\", \"waves_per_simd\": %d, \"ms\": %.3f, \"lane_instr_per_cu_per_clk\": %.1f, \"cycles_per_wave_instr_per_simd\": %.2f}\n",
              names[mode], wps, ms, per_cu_clk, 256.0 / per_cu_clk);
