@@ -102,6 +102,17 @@ int zk_ptr_on_device(amdzk_ctx* ctx, const void* p, const char* what) {
   return AMDZK_OK;
 }
 
+// One context = one HIP stream, and a host that keeps several proofs in flight uses several contexts. The HIP runtime
+// maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues, 4 unless the environment says otherwise, and kernels
+// of streams that share a queue wait for each other: 8 proofs in flight on 4 queues measure no better than 4
+// (profiles/r02j_hw_queues_sweep.txt). The variable is read when the runtime initialises, so it is set — never
+// overridden — when this library is loaded; a host that initialised HIP earlier sets it itself.
+namespace {
+struct HwQueuesDefault {
+  HwQueuesDefault() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+} hw_queues_default;
+}  // namespace
+
 extern "C" {
 
 int amdzk_version(void) { return 1000; }

@@ -151,6 +151,24 @@ struct amdzk_pk {
   Fr *ci = nullptr, *ct = nullptr;  // [L][n] compressed lookup input / table
   Fr *rnd = nullptr, *hq = nullptr, *hpieces = nullptr, *hpoly = nullptr, *frac = nullptr, *scratch = nullptr, *scan_tmp = nullptr;
   Fr *sets_L = nullptr, *sets_N = nullptr, *hx = nullptr;  // SHPLONK buffers
+  // What the multiopen argument derives from the key alone, built by the first proof (the polynomials live at fixed
+  // addresses in this key's workspace): the evaluation list, the query list and SHPLONK's rotation sets in terms of
+  // rotations. Only the ORDER of a set's points (upstream keeps them in a BTreeSet of field elements) depends on x.
+  struct Multiopen {
+    bool built = false;
+    std::vector<std::pair<const Fr*, int>> ev;      // (polynomial, rotation) in the order the evaluations are written
+    size_t n_written = 0;                           // ... of which the first n_written go to the transcript
+    std::vector<int> rots;                          // distinct rotations, first seen first
+    std::vector<uint32_t> ev_rot;                   // per evaluation: index into rots
+    std::vector<const Fr*> q_poly;                  // the queries, upstream order
+    std::vector<uint32_t> q_rot, q_ev;              // per query: index into rots / into ev
+    struct Set {
+      std::vector<uint32_t> rot_ids;                // the set's rotations (ascending index into rots)
+      std::vector<const Fr*> polys;                 // its polynomials, first seen first
+      std::vector<std::vector<uint32_t>> ev_idx;    // [poly][k]: evaluation of polys[poly] at rots[rot_ids[k]]
+    };
+    std::vector<Set> sets;                          // first seen first
+  } mo;
   Fr *lk_ts = nullptr, *lk_left = nullptr;  // lookup permutation: sorted tables, leftovers [L][n]
   uint32_t* lk_flags = nullptr;              // [4][L][n+8]
   int* d_err = nullptr;
@@ -1389,18 +1407,22 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
 
   // 0. vk, instances
   T.common_scalar(pk->transcript_repr);
-  {
-    std::vector<Fr> iv((size_t)I * n, Fr::zero());
+  if (I) {  // columns are zero beyond the caller's values: clear on the device, upload only what was given
+    ZK_HIP(ctx, hipMemsetAsync(pk->inst(), 0, (size_t)I * n * 32, ctx->stream));
+    std::vector<Fr> iv;
     for (uint32_t c = 0; c < I; c++) {
-      size_t len = instance_lens ? instance_lens[c] : 0;
+      const size_t len = instance_lens ? instance_lens[c] : 0;
       if (len > usable) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: instance column %u too long (InstanceTooLarge)", c);
+      if (!len) continue;
+      iv.resize(len);
       for (size_t i = 0; i < len; i++) {
-        memcpy(iv[(size_t)c * n + i].l, instances[c] + 4 * i, 32);
-        T.common_scalar(iv[(size_t)c * n + i]);
+        memcpy(iv[i].l, instances[c] + 4 * i, 32);
+        T.common_scalar(iv[i]);
       }
+      ZK_TRY(h2d_staged(ctx, pk, pk->inst() + (size_t)c * n, iv.data(), len * 32));
+      // without room in the pinned staging area the copy reads `iv` asynchronously: finish it before the next column reuses it
+      if (!pk->pin || len * 32 > pk->pin_cap) ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    ZK_TRY(h2d(ctx, pk->inst(), iv.data(), iv.size() * 32));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   // 1. advice: copy in, blind the unusable rows of every column, draw the (unused) blinds, commit
   if (A) {
@@ -1549,76 +1571,127 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
   }
   // 7. evaluations. One list of (polynomial, rotation) in proof order, then the two extra
   //    evaluations SHPLONK needs (h_poly at x; random at x is already in the list).
-  struct Q {
-    const Fr* poly;
-    int rot;
-    Fr point, eval;
-  };
-  std::vector<Q> ev;
-  auto addq = [&](const Fr* p, int rot) { ev.push_back(Q{p, rot, rotate_omega(pk, x, rot), Fr::zero()}); };
+  amdzk_pk::Multiopen& mo = pk->mo;
   Fr* adv_poly = pk->adv();
-  for (auto& q : pk->advice_queries) addq(adv_poly + (size_t)q.first * n, q.second);
-  for (auto& q : pk->fixed_queries) addq(pk->fixed_poly + (size_t)q.first * n, q.second);
-  addq(pk->rnd, 0);
-  for (uint32_t i = 0; i < S; i++) addq(pk->sigma_poly + (size_t)i * n, 0);
-  for (uint32_t s = 0; s < ns; s++) {
-    addq(pk->zp() + (size_t)s * n, 0);
-    addq(pk->zp() + (size_t)s * n, 1);
-    if (s + 1 < ns) addq(pk->zp() + (size_t)s * n, -(int)(bf + 1));
+  if (!mo.built) {
+    auto rot_id = [&](int rot) -> uint32_t {
+      for (size_t i = 0; i < mo.rots.size(); i++)
+        if (mo.rots[i] == rot) return (uint32_t)i;
+      mo.rots.push_back(rot);
+      return (uint32_t)mo.rots.size() - 1;
+    };
+    auto addq = [&](const Fr* p, int rot) {
+      mo.ev.push_back({p, rot});
+      mo.ev_rot.push_back(rot_id(rot));
+    };
+    for (auto& q : pk->advice_queries) addq(adv_poly + (size_t)q.first * n, q.second);
+    for (auto& q : pk->fixed_queries) addq(pk->fixed_poly + (size_t)q.first * n, q.second);
+    addq(pk->rnd, 0);
+    for (uint32_t i = 0; i < S; i++) addq(pk->sigma_poly + (size_t)i * n, 0);
+    for (uint32_t s = 0; s < ns; s++) {
+      addq(pk->zp() + (size_t)s * n, 0);
+      addq(pk->zp() + (size_t)s * n, 1);
+      if (s + 1 < ns) addq(pk->zp() + (size_t)s * n, -(int)(bf + 1));
+    }
+    for (uint32_t l = 0; l < L; l++) {
+      addq(pk->zl() + (size_t)l * n, 0);
+      addq(pk->zl() + (size_t)l * n, 1);
+      addq(pk->la() + (size_t)l * n, 0);
+      addq(pk->la() + (size_t)l * n, -1);
+      addq(pk->ls() + (size_t)l * n, 0);
+    }
+    mo.n_written = mo.ev.size();
+    addq(pk->hpoly, 0);
+    // 8. multiopen queries in upstream order
+    std::map<std::pair<const Fr*, int>, uint32_t> where;
+    for (size_t i = 0; i < mo.ev.size(); i++) where.emplace(mo.ev[i], (uint32_t)i);
+    bool missing = false;
+    auto addpq = [&](const Fr* p, int rot) {
+      auto it = where.find({p, rot});
+      if (it == where.end()) {
+        missing = true;
+        return;
+      }
+      mo.q_poly.push_back(p);
+      mo.q_rot.push_back(rot_id(rot));
+      mo.q_ev.push_back(it->second);
+    };
+    for (auto& q : pk->advice_queries) addpq(adv_poly + (size_t)q.first * n, q.second);
+    for (uint32_t s = 0; s < ns; s++) {
+      addpq(pk->zp() + (size_t)s * n, 0);
+      addpq(pk->zp() + (size_t)s * n, 1);
+    }
+    for (int s = (int)ns - 2; s >= 0; s--) addpq(pk->zp() + (size_t)s * n, -(int)(bf + 1));
+    for (uint32_t l = 0; l < L; l++) {
+      addpq(pk->zl() + (size_t)l * n, 0);
+      addpq(pk->la() + (size_t)l * n, 0);
+      addpq(pk->ls() + (size_t)l * n, 0);
+      addpq(pk->la() + (size_t)l * n, -1);
+      addpq(pk->zl() + (size_t)l * n, 1);
+    }
+    for (auto& q : pk->fixed_queries) addpq(pk->fixed_poly + (size_t)q.first * n, q.second);
+    for (uint32_t i = 0; i < S; i++) addpq(pk->sigma_poly + (size_t)i * n, 0);
+    addpq(pk->hpoly, 0);
+    addpq(pk->rnd, 0);
+    if (missing) {
+      mo = amdzk_pk::Multiopen();
+      ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: a multiopen query has no evaluation");
+    }
+    // shplonk construct_intermediate_sets, in terms of rotations: the polynomials with their sets of rotations
+    // (first seen first), then the distinct sets with their polynomials (first seen first)
+    std::vector<const Fr*> cr_poly;
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> cr_rots;  // (rot id, ev index), ascending rot id
+    std::map<const Fr*, uint32_t> cr_of;
+    for (size_t i = 0; i < mo.q_poly.size(); i++) {
+      auto it = cr_of.find(mo.q_poly[i]);
+      if (it == cr_of.end()) {
+        it = cr_of.emplace(mo.q_poly[i], (uint32_t)cr_poly.size()).first;
+        cr_poly.push_back(mo.q_poly[i]);
+        cr_rots.emplace_back();
+      }
+      auto& v = cr_rots[it->second];
+      const std::pair<uint32_t, uint32_t> e{mo.q_rot[i], mo.q_ev[i]};
+      auto pos = std::lower_bound(v.begin(), v.end(), e, [](const auto& x1, const auto& x2) { return x1.first < x2.first; });
+      if (pos == v.end() || pos->first != e.first) v.insert(pos, e);
+    }
+    for (size_t c = 0; c < cr_poly.size(); c++) {
+      std::vector<uint32_t> ids, evs;
+      for (auto& e : cr_rots[c]) ids.push_back(e.first), evs.push_back(e.second);
+      amdzk_pk::Multiopen::Set* hit = nullptr;
+      for (auto& st : mo.sets)
+        if (st.rot_ids == ids) hit = &st;
+      if (!hit) {
+        mo.sets.emplace_back();
+        hit = &mo.sets.back();
+        hit->rot_ids = ids;
+      }
+      hit->polys.push_back(cr_poly[c]);
+      hit->ev_idx.push_back(evs);
+    }
+    mo.built = true;
   }
-  for (uint32_t l = 0; l < L; l++) {
-    addq(pk->zl() + (size_t)l * n, 0);
-    addq(pk->zl() + (size_t)l * n, 1);
-    addq(pk->la() + (size_t)l * n, 0);
-    addq(pk->la() + (size_t)l * n, -1);
-    addq(pk->ls() + (size_t)l * n, 0);
+  // the points x * omega^rot, once per distinct rotation
+  const size_t nrot = mo.rots.size();
+  std::vector<Fr> rot_pt(nrot);
+  std::vector<std::array<uint64_t, 4>> rot_canon(nrot);
+  for (size_t r = 0; r < nrot; r++) {
+    rot_pt[r] = rotate_omega(pk, x, mo.rots[r]);
+    rot_canon[r] = canon(rot_pt[r]);
   }
-  const size_t n_written = ev.size();
-  addq(pk->hpoly, 0);
+  std::vector<Fr> evals(mo.ev.size());
   {
-    const size_t nq = ev.size();
+    const size_t nq = mo.ev.size();
     if (nq > pk->ptrs_cap || 2 * nq > pk->small_cap) ZK_FAIL(ctx, AMDZK_E_NOMEM, "create_proof: too many queries (%zu)", nq);
     std::vector<const Fr*> pp(nq);
     std::vector<Fr> pts(nq);
-    for (size_t i = 0; i < nq; i++) pp[i] = ev[i].poly, pts[i] = ev[i].point;
+    for (size_t i = 0; i < nq; i++) pp[i] = mo.ev[i].first, pts[i] = rot_pt[mo.ev_rot[i]];
     ZK_TRY(h2d_staged(ctx, pk, pk->ptrs, pp.data(), nq * sizeof(Fr*)));
     ZK_TRY(upload_small(pts, 0));
     ZK_TRY(zk_poly_eval(ctx, (const Fr* const*)pk->ptrs, pk->small, pk->small + nq, nq, (uint32_t)n));
-    std::vector<Fr> res(nq);
-    ZK_TRY(d2h(ctx, res.data(), pk->small + nq, nq * 32));
-    for (size_t i = 0; i < nq; i++) ev[i].eval = res[i];
-    for (size_t i = 0; i < n_written; i++) T.write_scalar(ev[i].eval);
+    ZK_TRY(d2h(ctx, evals.data(), pk->small + nq, nq * 32));
+    for (size_t i = 0; i < mo.n_written; i++) T.write_scalar(evals[i]);
   }
-  auto eval_of = [&](const Fr* p, int rot) -> Fr {
-    for (auto& q : ev)
-      if (q.poly == p && q.rot == rot) return q.eval;
-    return Fr::zero();
-  };
   tick("evals");
-  // 8. multiopen queries in upstream order
-  struct PQ {
-    const Fr* poly;
-    Fr point, eval;
-  };
-  std::vector<PQ> queries;
-  auto addpq = [&](const Fr* p, int rot) { queries.push_back(PQ{p, rotate_omega(pk, x, rot), eval_of(p, rot)}); };
-  for (auto& q : pk->advice_queries) addpq(adv_poly + (size_t)q.first * n, q.second);
-  for (uint32_t s = 0; s < ns; s++) {
-    addpq(pk->zp() + (size_t)s * n, 0);
-    addpq(pk->zp() + (size_t)s * n, 1);
-  }
-  for (int s = (int)ns - 2; s >= 0; s--) addpq(pk->zp() + (size_t)s * n, -(int)(bf + 1));
-  for (uint32_t l = 0; l < L; l++) {
-    addpq(pk->zl() + (size_t)l * n, 0);
-    addpq(pk->la() + (size_t)l * n, 0);
-    addpq(pk->ls() + (size_t)l * n, 0);
-    addpq(pk->la() + (size_t)l * n, -1);
-    addpq(pk->zl() + (size_t)l * n, 1);
-  }
-  for (auto& q : pk->fixed_queries) addpq(pk->fixed_poly + (size_t)q.first * n, q.second);
-  for (uint32_t i = 0; i < S; i++) addpq(pk->sigma_poly + (size_t)i * n, 0);
-  addpq(pk->hpoly, 0);
-  addpq(pk->rnd, 0);
 
   // 9a. GWC (multiopen/gwc/prover.rs [UP]): v <- transcript; queries grouped by point in first-seen order;
   // per point z:  W_z = (sum_j v^j p_j - sum_j v^j p_j(z)) / (X - z), committed and written in that order.
@@ -1629,18 +1702,17 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
       std::vector<const Fr*> polys;
       std::vector<Fr> evals;
     };
-    std::vector<PS> psets;
-    for (auto& q : queries) {
-      const std::array<uint64_t, 4> key = canon(q.point);
-      PS* hit = nullptr;
-      for (auto& ps : psets)
-        if (ps.key == key) hit = &ps;
-      if (!hit) {
-        psets.push_back(PS{key, q.point, {}, {}});
-        hit = &psets.back();
+    std::vector<PS> psets;  // one per distinct point (= distinct rotation), first seen first
+    std::vector<int> ps_of_rot(nrot, -1);
+    for (size_t i = 0; i < mo.q_poly.size(); i++) {
+      const uint32_t r = mo.q_rot[i];
+      if (ps_of_rot[r] < 0) {
+        ps_of_rot[r] = (int)psets.size();
+        psets.push_back(PS{rot_canon[r], rot_pt[r], {}, {}});
       }
-      hit->polys.push_back(q.poly);
-      hit->evals.push_back(q.eval);
+      PS& hit = psets[ps_of_rot[r]];
+      hit.polys.push_back(mo.q_poly[i]);
+      hit.evals.push_back(evals[mo.q_ev[i]]);
     }
     const size_t np = psets.size();
     if (np > 16) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "create_proof: more than 16 opening points");
@@ -1679,74 +1751,38 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
   } else
   // 9b. SHPLONK (multiopen/shplonk/prover.rs [UP])
   {
-    // construct_intermediate_sets
-    struct CR {
-      const Fr* poly;
-      std::vector<std::array<uint64_t, 4>> pts;  // sorted, distinct (canonical)
-    };
-    std::vector<CR> com_rot;
-    std::vector<std::array<uint64_t, 4>> super;
-    auto insert_sorted = [](std::vector<std::array<uint64_t, 4>>& v, const std::array<uint64_t, 4>& p) {
-      auto it = std::lower_bound(v.begin(), v.end(), p, fr_less_canon);
-      if (it == v.end() || *it != p) v.insert(it, p);
-    };
-    std::vector<std::array<uint64_t, 4>> qcanon(queries.size());
-    for (size_t i = 0; i < queries.size(); i++) {
-      qcanon[i] = canon(queries[i].point);
-      insert_sorted(super, qcanon[i]);
-      bool found = false;
-      for (auto& cr : com_rot)
-        if (cr.poly == queries[i].poly) {
-          insert_sorted(cr.pts, qcanon[i]);
-          found = true;
-          break;
-        }
-      if (!found) com_rot.push_back(CR{queries[i].poly, {qcanon[i]}});
-    }
-    struct RS {
-      std::vector<std::array<uint64_t, 4>> pts;
-      std::vector<const Fr*> polys;
-    };
-    std::vector<RS> rsets;
-    for (auto& cr : com_rot) {
-      bool found = false;
-      for (auto& rs : rsets)
-        if (rs.pts == cr.pts) {
-          rs.polys.push_back(cr.poly);
-          found = true;
-          break;
-        }
-      if (!found) rsets.push_back(RS{cr.pts, {cr.poly}});
-    }
-    if (rsets.size() > 16) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "create_proof: more than 16 rotation sets");
-    auto point_fr = [&](const std::array<uint64_t, 4>& c) {
-      Fr r;
-      memcpy(r.l, c.data(), 32);
-      return to_mont(r);
-    };
-    std::map<std::pair<const Fr*, std::array<uint64_t, 4>>, Fr> eval_map;
-    for (size_t i = 0; i < queries.size(); i++) eval_map[{queries[i].poly, qcanon[i]}] = queries[i].eval;
+    // construct_intermediate_sets: the sets are the key's (mo.sets); their points, and the super point set, are kept
+    // in ascending order of the canonical field elements as upstream's BTreeSets do
+    const size_t nr = mo.sets.size();
+    if (nr > 16) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "create_proof: more than 16 rotation sets");
+    auto by_point = [&](uint32_t r1, uint32_t r2) { return fr_less_canon(rot_canon[r1], rot_canon[r2]); };
+    std::vector<uint32_t> super(nrot);
+    for (size_t r = 0; r < nrot; r++) super[r] = (uint32_t)r;
+    std::sort(super.begin(), super.end(), by_point);
     Fr ys = T.squeeze_challenge();
     Fr v = T.squeeze_challenge();
     trace_fr("shplonk_y", ys);
     trace_fr("shplonk_v", v);
-    const size_t nr = rsets.size();
     std::vector<std::vector<Fr>> set_pts(nr);
     std::vector<std::vector<std::vector<Fr>>> lows(nr);  // [set][commitment] low-degree equivalent
     for (size_t i = 0; i < nr; i++) {
-      for (auto& c : rsets[i].pts) set_pts[i].push_back(point_fr(c));
+      const amdzk_pk::Multiopen::Set& st = mo.sets[i];
+      const size_t m = st.rot_ids.size();
+      std::vector<uint32_t> order(m);  // positions in rot_ids, by ascending point
+      for (size_t t = 0; t < m; t++) order[t] = (uint32_t)t;
+      std::sort(order.begin(), order.end(), [&](uint32_t t1, uint32_t t2) { return by_point(st.rot_ids[t1], st.rot_ids[t2]); });
+      for (size_t t = 0; t < m; t++) set_pts[i].push_back(rot_pt[st.rot_ids[order[t]]]);
       // Lagrange basis of the set's points, once per set: low_ij = sum_t evals_t * basis_t
-      const size_t m = set_pts[i].size();
       std::vector<std::vector<Fr>> basis(m);
       for (size_t t = 0; t < m; t++) {
         std::vector<Fr> unit(m, Fr::zero());
         unit[t] = Fr::one();
         basis[t] = lagrange_interpolate(set_pts[i], unit);
       }
-      for (auto* poly : rsets[i].polys) {
+      for (size_t j = 0; j < st.polys.size(); j++) {
         std::vector<Fr> low(m, Fr::zero());
         for (size_t t = 0; t < m; t++) {
-          const Fr e = eval_map[{poly, rsets[i].pts[t]}];
+          const Fr e = evals[st.ev_idx[j][order[t]]];
           for (size_t d = 0; d < m; d++) low[d] = add(low[d], mul(e, basis[t][d]));
         }
         lows[i].push_back(std::move(low));
@@ -1755,7 +1791,7 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     // L_i = sum_j y^j P_ij ; N_i = (L_i - sum_j y^j R_ij) / prod (X - p)
     size_t maxm = 0;
     for (size_t i = 0; i < nr; i++) {
-      const size_t m = rsets[i].polys.size();
+      const size_t m = mo.sets[i].polys.size();
       if (m > pk->ptrs_cap || m > pk->small_cap / 2) ZK_FAIL(ctx, AMDZK_E_NOMEM, "create_proof: rotation set too large");
       std::vector<Fr> cf(m);
       Fr cur = Fr::one();
@@ -1766,7 +1802,7 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
         cur = mul(cur, ys);
       }
       maxm = std::max(maxm, set_pts[i].size());
-      ZK_TRY(h2d_staged(ctx, pk, pk->ptrs, rsets[i].polys.data(), m * sizeof(Fr*)));
+      ZK_TRY(h2d_staged(ctx, pk, pk->ptrs, mo.sets[i].polys.data(), m * sizeof(Fr*)));
       ZK_TRY(upload_small(cf, 0));
       ZK_TRY(upload_small(lowsum, m));
       Fr* Li = pk->sets_L + i * n;
@@ -1807,14 +1843,14 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     trace_fr("u", u);
     // l(X) = sum_i v^i z_i (L_i - r_i) - zt(u) h(X);  then / (X - u) / z_0
     Fr zt = Fr::one();
-    for (auto& c : super) zt = mul(zt, sub(u, point_fr(c)));
+    for (uint32_t r : super) zt = mul(zt, sub(u, rot_pt[r]));
     std::vector<const Fr*> pp(nr + 1);
     std::vector<Fr> cf(nr + 1);
     Fr cur = Fr::one(), z0 = Fr::one(), cterm = Fr::zero();
     for (size_t i = 0; i < nr; i++) {
       Fr zi = Fr::one();
-      for (auto& c : super)
-        if (!std::binary_search(rsets[i].pts.begin(), rsets[i].pts.end(), c, fr_less_canon)) zi = mul(zi, sub(u, point_fr(c)));
+      for (uint32_t r : super)
+        if (!std::binary_search(mo.sets[i].rot_ids.begin(), mo.sets[i].rot_ids.end(), r)) zi = mul(zi, sub(u, rot_pt[r]));
       if (i == 0) z0 = zi;
       Fr ri = Fr::zero(), yp = Fr::one();
       for (size_t j = 0; j < lows[i].size(); j++) {

@@ -45,8 +45,8 @@ SHAPE_NAMES = ("full", "k15", "k18")
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20,
-                    help="timed proofs per GPU; the default gives five full rounds of 4 in flight, so pipeline fill/drain is a small share")
+    ap.add_argument("--steps", type=int, default=40,
+                    help="timed proofs per GPU; the default gives four full rounds of 10 in flight, so pipeline fill/drain is a small share")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--shape", default="full", choices=SHAPE_NAMES,
                     help="full = composite Aadhaar verifier budget at k = 15 (the metric's configuration); k15 / k18 = RSA-SHA256 sub-circuit shapes")
@@ -56,7 +56,8 @@ def parse_args(argv=None):
     ap.add_argument("--witnesses", type=int, default=0, help="distinct resident witnesses per GPU the steps cycle through (0 = auto: 4, or all of them with --batch)")
     ap.add_argument("--concurrency", type=int, default=int(os.environ.get("AMDZK_BENCH_CONCURRENCY", "0")),
                     help="proofs in flight per GPU (each on its own amdzk context / HIP stream / proving-key workspace); "
-                         "0 = auto: a divisor of --steps among 4, 5, 3, 6 (so the timed steps form whole rounds), else 4")
+                         "0 = auto: the largest divisor of --steps between 6 and 12 (so the timed steps form whole rounds), else "
+                         "one of 5, 4, 3, else 8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stream-pass", action="store_true", help="skip the PCIe-inclusive pass (one witness upload per proof)")
     return ap.parse_args(argv)
@@ -282,6 +283,10 @@ def run_rank(args):
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N`, or under "
                          "torch.distributed.run with --nproc-per-node equal to --gpus)" % (args.gpus, world))
+    # The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default): with more
+    # proofs in flight than queues, kernels of different proofs queue up behind each other. Must be set before the
+    # runtime initialises (libamdzk.so's own initialiser does the same for hosts that load it first).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
     import torch.distributed as dist
 
@@ -308,8 +313,10 @@ def run_rank(args):
         steps = args.batch // world
     P = args.concurrency
     if P <= 0:
-        divs = [d for d in (4, 5, 3, 6) if steps % d == 0]  # 4 in flight measured best (profiles/r01e)
-        P = divs[0] if divs else min(4, max(1, steps))
+        # throughput grows slowly past 8 in flight once the runtime has as many hardware queues (profiles/r02j_hw_queues_sweep.txt:
+        # 4 / 8 / 12 / 16 in flight = 69 / 74 / 74 / 75 proofs/s); a last round with idle workers costs more than that
+        divs = [d for d in (12, 11, 10, 9, 8, 7, 6, 5, 4, 3) if steps % d == 0]
+        P = divs[0] if divs else min(8, max(1, steps))
     # global proof index of (step s, rank r) = s*world + r (round-robin, batch.shard_indices). With --batch the witness
     # of proof g has seed g; otherwise the rank cycles through nw witnesses of its own.
     nw = args.witnesses or (steps if args.batch else min(4, steps))
