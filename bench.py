@@ -468,12 +468,29 @@ def roofline(prover, desc):
             "avg_launch_ms": round(total_ms / launches, 4), "launches_per_step": launches,
             # what the kernel is actually limited by: VALU issue. cycles per VALU wave-instruction =
             # launch time x 1024 SIMDs x 2.4 GHz / SQ_INSTS_VALU per launch; ~5 means the SIMDs issue back to back
-            # (v_mad_u64_u32 takes 5.3 cycles, plain VALU 2.7: profiles/r01f_microbench.jsonl)
+            # (v_mad_u64_u32 takes 5.4-6.0 cycles, plain 32-bit VALU 2.5-4.2: profiles/r02i_instruction_rates_mb_isa.jsonl)
             "valu_wave_insts_per_launch": pmc.get("valu"),
             "valu_issue_cycles_per_inst": round(avg_s * 1024 * 2.4e9 / pmc["valu"], 2) if pmc.get("valu") else None,
+            "issue_bound": issue_bound(pmc, avg_s),
             "gpu_busy_ms_per_step": round(gpu_ms, 3), "wall_ms_profiled_step": round(wall_prof, 3),
             "per_kernel_ms": {kname: round(v[1], 3) for kname, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
     return roof, wall_prof
+
+
+MAD_CYCLES, OTHER_VALU_CYCLES = 5.4, 2.7  # measured issue rates, cycles per wave-instruction and SIMD (tools/mb_isa.hip)
+
+
+def issue_bound(pmc, avg_s):
+    """The limit the dominant kernel is actually at: the time its VALU instructions take to ISSUE on 1024 SIMDs at
+    2.4 GHz — SQ_INSTS_VALU per launch (PMC) split by the multiply-add share of its inner loop (static, from the
+    assembly; stamped into the same summary by tools/summarize_prof.py), each class at its measured issue rate —
+    against the measured launch time. frac near 1 = nothing but fewer instructions makes the kernel faster."""
+    if not pmc.get("valu") or pmc.get("mad_share") is None:
+        return None
+    share = pmc["mad_share"]
+    model_s = pmc["valu"] * (share * MAD_CYCLES + (1.0 - share) * OTHER_VALU_CYCLES) / (1024 * 2.4e9)
+    return {"mad_share_of_valu": share, "cycles_per_mad": MAD_CYCLES, "cycles_per_other_valu": OTHER_VALU_CYCLES,
+            "model_ms_per_launch": round(model_s * 1e3, 4), "frac": round(model_s / avg_s, 4)}
 
 
 def kernel_src_hash():
@@ -510,6 +527,13 @@ def pmc_counters(kernel):
                 if first.strip().split("=", 1)[1] != want:
                     stale = stale or os.path.basename(path)
                     continue
+                mad_share = None
+                pos = f.tell()
+                second = f.readline()
+                if second.startswith("# msm_accum_l1_mad_share="):
+                    mad_share = float(second.split("=", 1)[1].split()[0])
+                else:
+                    f.seek(pos)
                 for row in csv.DictReader(f):
                     if row["kernel"] == names.get(kernel, kernel):
                         out = {"source": "profiles/%s (rocprofv3 --pmc, raw, per launch; kernel sources %s)" % (os.path.basename(path), want)}
@@ -517,6 +541,8 @@ def pmc_counters(kernel):
                             out["traffic"] = round((float(row["FETCH_SIZE_KiB_per_launch_raw"]) + float(row["WRITE_SIZE_KiB_per_launch_raw"])) * 1024)
                         if row.get("SQ_INSTS_VALU_per_launch"):
                             out["valu"] = round(float(row["SQ_INSTS_VALU_per_launch"]))
+                        if mad_share is not None and kernel == "msm_accum_l1":
+                            out["mad_share"] = mad_share
                         return out
         except OSError:
             continue

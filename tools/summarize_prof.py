@@ -30,6 +30,41 @@ def db(src, kind):
     return sqlite3.connect(p) if os.path.exists(p) else None
 
 
+def mad_share_of_hot_loop():
+    """Share of v_mad_u64_u32 among the VALU instructions of msm_accum_seg_kernel<true>'s mixed-addition block (the
+    basic block with the most multiply-adds), from hipcc's gfx950 assembly of this tree's msm.hip. None without hipcc."""
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        return None
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "anon-aadhaar-halo2_amd", "csrc")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "msm.s")
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-DAMDZK_ASM_PRODUCT", "-I" + os.path.join(root, "include"), "-I" + csrc,
+                            "--cuda-device-only", "-S", os.path.join(csrc, "msm.hip"), "-o", out], capture_output=True, timeout=900)
+        if r.returncode != 0:
+            return None
+        text = open(out).read()
+    m = re.search(r"^(_Z\w*msm_accum_seg_kernelILb1E\w*):[^\n]*\n(.*?)^\.Lfunc_end\d+:", text, re.S | re.M)
+    if not m:
+        return None
+    best = (0, 0)
+    mad = valu = 0
+    for ln in m.group(2).splitlines() + [".LBB_end:"]:
+        t = ln.split(";")[0].strip()
+        if re.match(r"^\.LBB\w+:", t):
+            if mad > best[0]:
+                best = (mad, valu)
+            mad = valu = 0
+        elif t.startswith("v_"):
+            valu += 1
+            mad += t.startswith("v_mad_u64_u32")
+    return (best[0] / best[1], best[0], best[1]) if best[1] else None
+
+
 def main():
     src, tag = sys.argv[1], sys.argv[2]
     proofs = float(sys.argv[3]) if len(sys.argv) > 3 else 3.0  # warm-up + timed + the profiled extra proof of bench.py
@@ -68,6 +103,9 @@ def main():
     path = os.path.join("profiles", tag + "_kernel_summary.csv")
     with open(path, "w") as o:
         o.write("# kernel_src_sha256=%s\n" % bench.kernel_src_hash())
+        share = mad_share_of_hot_loop()
+        if share:
+            o.write("# msm_accum_l1_mad_share=%.4f  (%d v_mad_u64_u32 of %d VALU instructions in the mixed-addition block, hipcc -S of this tree)\n" % share)
         o.write("kernel,calls,avg_ms,pct_of_gpu_time,FETCH_SIZE_KiB_per_launch_raw,WRITE_SIZE_KiB_per_launch_raw,"
                 "hbm_MB_per_launch_corrected(2*FETCH+WRITE),SQ_INSTS_VALU_per_launch\n")
         for k, (calls, avg_ms, pct) in stats.items():
