@@ -756,6 +756,8 @@ static int quotient_pieces(amdzk_ctx* ctx, amdzk_pk* pk) {
   ZK_TRY(zk_coeff_to_cosets_r261(ctx, pk->dom, pk->P, pk->n, pk->PC, pk->ext, pk->NP));
   ZK_TRY(upload_consts261(ctx, pk));
   ZK_TRY(upload_ypow(ctx, pk));
+  // the program writes h where its first group of terms is flushed: a constraint system without a single term has none
+  if (!pk->h_terms) ZK_HIP(ctx, hipMemsetAsync(pk->hq, 0, (size_t)pk->ext * 32, ctx->stream));
   ZK_TRY(run_program(ctx, pk, pk->prog_h, true, nullptr, pk->hq, "expr_evaluate_h"));
   ZK_TRY(zk_cosets_to_pieces(ctx, pk->dom, pk->hq, pk->hpieces, pk->qdeg));
   return AMDZK_OK;
@@ -1226,7 +1228,8 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
   KG_TRY(upload_program(ctx, pk, pk->prog_h, true));
   if (getenv("AMDZK_DUMP_PROG")) {  // debugging aid: what the compiled h(X) program is made of
     static const char* names[] = {"END", "PUSH_COL", "PUSH_CONST", "ADD", "SUB", "MUL", "NEG", "MUL_CONST", "ADD_CONST", "MUL_COL",
-                                  "ADD_COL", "SUB_COL", "ACC", "STORE", "SQR", "PUSH_HOT", "MUL_HOT"};
+                                  "ADD_COL", "SUB_COL", "ACC", "STORE", "SQR", "PUSH_HOT", "MUL_HOT", "REDUCE", "SUB_BIG", "NEG_BIG",
+                                  "WACC", "WFLUSH"};
     std::map<uint32_t, size_t> hist;
     std::map<std::pair<uint32_t, uint32_t>, size_t> pairs;
     const auto& w = pk->prog_h.words;
@@ -1235,8 +1238,8 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
       if (i + 1 < w.size()) pairs[{w[i] >> 24, w[i + 1] >> 24}]++;
     }
     fprintf(stderr, "[amdzk] prog_h: %zu instructions, stack depth %u\n", w.size(), pk->prog_h.depth);
-    for (auto& kv : hist) fprintf(stderr, "[amdzk]   %-10s %zu\n", kv.first < 17 ? names[kv.first] : "?", kv.second);
-    auto is_mul = [](uint32_t o) { return o == OP_MUL || o == OP_MUL_CONST || o == OP_MUL_COL || o == OP_MUL_HOT || o == OP_SQR || o == OP_ACC; };
+    for (auto& kv : hist) fprintf(stderr, "[amdzk]   %-10s %zu\n", kv.first < 22 ? names[kv.first] : "?", kv.second);
+    auto is_mul = [](uint32_t o) { return o == OP_MUL || o == OP_MUL_CONST || o == OP_MUL_COL || o == OP_MUL_HOT || o == OP_SQR || o == OP_WACC; };
     size_t mm = 0;
     for (auto& kv : pairs)
       if (is_mul(kv.first.first) && is_mul(kv.first.second)) {
