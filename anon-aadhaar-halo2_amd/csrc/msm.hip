@@ -940,14 +940,18 @@ int zk_msm_dev_xyzz(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const Fr* d
   if ((uint64_t)W * srs->n >= (1ull << 31)) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "msm: table too large for 31-bit ids");
 
   // task sizes: level 1 adds T1 table points per thread, levels 2.. fold TL partial sums per thread;
-  // all levels use the balanced segmented kernel. Measured (profiles/r01g_msm_task_sweep.txt): with
-  // several proofs in flight throughput is flat in T1 (the chip is work-bound), and every extra
-  // folding level costs a latency-bound launch, so: big tasks, two folding levels.
+  // all levels use the balanced segmented kernel. Every extra folding level costs a latency-bound launch, so two
+  // folding levels; T1 = 12 for the large batches (profiles/r02j_msm_task_size.txt: T1 = 8 / 12 / 16 / 32 / 48 take
+  // 5.8 / 5.7 / 6.5 / 7.1 / 7.8 ms per proof in level 1 against 2.4 / 2.1 / 1.9 / 1.6 / 1.6 in the folds — a task of 32
+  // additions leaves the last of its few thousand wavefronts running alone — and 76.9 against 76.0 proofs/s for
+  // 12 against 16 with ten proofs in flight). e_total is a capacity: zero digits never become entries.
   const size_t e_total = ecap * ncols;
   uint32_t T1 = 4;
-  while (T1 < 32 && e_total / T1 > 262144) T1 <<= 1;
+  if (e_total > (size_t)4 * 262144) T1 = 8;
+  if (e_total > (size_t)8 * 262144) T1 = 12;
   if (const char* e = getenv("AMDZK_MSM_T1")) T1 = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : T1;
-  const uint32_t TL = 8;
+  uint32_t TL = 6;  // 4 / 6 / 8 / 12 / 16 prove at the same rate (76.7-78.0 proofs/s); 6 has the shortest proof (profiles/r02j_msm_task_size.txt)
+  if (const char* e = getenv("AMDZK_MSM_TL")) TL = (uint32_t)atoi(e) > 1 ? (uint32_t)atoi(e) : TL;
   constexpr int NLEV = 3;  // level 1 + two folding levels, then the per-bucket final
   size_t cap[NLEV + 1];
   cap[0] = ecap;
