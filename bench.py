@@ -468,7 +468,7 @@ def roofline(prover, desc):
             "avg_launch_ms": round(total_ms / launches, 4), "launches_per_step": launches,
             # what the kernel is actually limited by: VALU issue. cycles per VALU wave-instruction =
             # launch time x 1024 SIMDs x 2.4 GHz / SQ_INSTS_VALU per launch; ~5 means the SIMDs issue back to back
-            # (v_mad_u64_u32 takes 5.4-6.0 cycles, plain 32-bit VALU 2.5-4.2: profiles/r02i_instruction_rates_mb_isa.jsonl)
+            # (v_mad_u64_u32 issues at 4.3 cycles at best, plain 32-bit VALU at 2.5-4.2: profiles/r02k_instruction_rates_mb_isa.jsonl)
             "valu_wave_insts_per_launch": pmc.get("valu"),
             "valu_issue_cycles_per_inst": round(avg_s * 1024 * 2.4e9 / pmc["valu"], 2) if pmc.get("valu") else None,
             "issue_bound": issue_bound(pmc, avg_s),
@@ -477,20 +477,22 @@ def roofline(prover, desc):
     return roof, wall_prof
 
 
-MAD_CYCLES, OTHER_VALU_CYCLES = 5.4, 2.7  # measured issue rates, cycles per wave-instruction and SIMD (tools/mb_isa.hip)
+MAD_CYCLES = 4.3  # v_mad_u64_u32, cycles per wave-instruction and SIMD at its peak (8 independent chains, 4-8 waves per SIMD:
+                  # profiles/r02k_instruction_rates_mb_isa.jsonl; 5.3-5.8 with 4 chains, whatever register takes the carry-out)
 
 
 def issue_bound(pmc, avg_s):
-    """The limit the dominant kernel is actually at: the time its VALU instructions take to ISSUE on 1024 SIMDs at
-    2.4 GHz — SQ_INSTS_VALU per launch (PMC) split by the multiply-add share of its inner loop (static, from the
-    assembly; stamped into the same summary by tools/summarize_prof.py), each class at its measured issue rate —
-    against the measured launch time. frac near 1 = nothing but fewer instructions makes the kernel faster."""
+    """The limit the dominant kernel is actually at: its multiply-adds cannot issue faster than MAD_CYCLES each on
+    1024 SIMDs at 2.4 GHz. mads per launch = SQ_INSTS_VALU per launch (PMC) x the multiply-add share of the kernel's
+    inner loop (static, from the assembly; stamped into the same summary by tools/summarize_prof.py). frac = that
+    lower bound / the measured launch time: the rest is the other VALU instructions (carry extraction, sums,
+    unpacking) and the dependent-issue stalls of the one-accumulator product."""
     if not pmc.get("valu") or pmc.get("mad_share") is None:
         return None
     share = pmc["mad_share"]
-    model_s = pmc["valu"] * (share * MAD_CYCLES + (1.0 - share) * OTHER_VALU_CYCLES) / (1024 * 2.4e9)
-    return {"mad_share_of_valu": share, "cycles_per_mad": MAD_CYCLES, "cycles_per_other_valu": OTHER_VALU_CYCLES,
-            "model_ms_per_launch": round(model_s * 1e3, 4), "frac": round(model_s / avg_s, 4)}
+    model_s = pmc["valu"] * share * MAD_CYCLES / (1024 * 2.4e9)
+    return {"mad_share_of_valu": share, "peak_cycles_per_mad": MAD_CYCLES, "mads_per_launch": round(pmc["valu"] * share),
+            "mad_issue_ms_per_launch": round(model_s * 1e3, 4), "frac": round(model_s / avg_s, 4)}
 
 
 def kernel_src_hash():

@@ -79,14 +79,14 @@ def test_failed_rank_fails_the_launch():
 
 
 def test_issue_bound_model_and_stamped_summary():
-    """roofline.issue_bound: VALU wave-instructions per launch split by the multiply-add share of the inner loop, each
-    class at its measured issue rate, against the launch time; the newest committed PMC summary must carry this
+    """roofline.issue_bound: the multiply-adds of a launch (VALU wave-instructions x their share of the inner loop) at
+    their peak issue rate, against the launch time; the newest committed PMC summary must carry this
     build's kernel-source hash AND the share, or bench.py reports nulls (never another build's counters)."""
     import bench
     pmc = {"valu": 430213208, "mad_share": 0.7125}
     ib = bench.issue_bound(pmc, 0.865e-3)
-    want = 430213208 * (0.7125 * bench.MAD_CYCLES + 0.2875 * bench.OTHER_VALU_CYCLES) / (1024 * 2.4e9)
-    assert abs(ib["model_ms_per_launch"] - want * 1e3) < 1e-3 and 0.9 < ib["frac"] < 1.0
+    want = 430213208 * 0.7125 * bench.MAD_CYCLES / (1024 * 2.4e9)
+    assert abs(ib["mad_issue_ms_per_launch"] - want * 1e3) < 1e-3 and 0.5 < ib["frac"] < 1.0
     assert bench.issue_bound({"valu": None}, 1e-3) is None and bench.issue_bound({"valu": 1}, 1e-3) is None
     got = bench.pmc_counters("msm_accum_l1")
     if "traffic" in got:  # the committed summary is of these sources
