@@ -45,8 +45,8 @@ SHAPE_NAMES = ("full", "k15", "k18")
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40,
-                    help="timed proofs per GPU; the default gives four full rounds of 10 in flight, so pipeline fill/drain is a small share")
+    ap.add_argument("--steps", type=int, default=48,
+                    help="timed proofs per GPU; the default gives four full rounds of 12 in flight, so pipeline fill/drain is a small share")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--shape", default="full", choices=SHAPE_NAMES,
                     help="full = composite Aadhaar verifier budget at k = 15 (the metric's configuration); k15 / k18 = RSA-SHA256 sub-circuit shapes")
