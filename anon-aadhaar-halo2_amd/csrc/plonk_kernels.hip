@@ -1,19 +1,20 @@
 // Device kernels of the PLONK-specific part of create_proof (halo2_proofs 0.2.0 @ v2023_01_20 [UP],
 // /root/reference/Cargo.lock:469-471):
 //
-//   expr_eval_kernel   — plonk::evaluation::Evaluator::evaluate_h (a7) and every other "evaluate an
-//                        expression on all rows" loop of the prover (lookup compression a9, the
-//                        numerators/denominators of the permutation and lookup grand products a8):
-//                        one straight-line stack program, executed by every row in lock step.
+//   expr_eval_limbs_kernel — plonk::evaluation::Evaluator::evaluate_h (a7): the whole h(X) numerator as one
+//                        straight-line stack program on the quotient cosets, executed by every row in lock step.
+//   expr_eval_kernel   — every other "evaluate an expression on all rows" loop of the prover (lookup
+//                        compression a9, the numerators/denominators of the permutation and lookup grand
+//                        products a8), the same way on the Lagrange domain.
 //   batch_invert_kernel, scan_* kernels — BatchInvert + the running products z(X) (a8, a9)
 //   poly_eval_kernel   — arithmetic::eval_polynomial for all (polynomial, point) queries at once (a11)
 //   lincomb_kernel, kate_div_kernel, small helpers — SHPLONK's polynomial algebra (a12)
 //
 // Upstream walks a per-row "calculation graph" on CPU threads; here the host compiles the whole h(X)
-// numerator (custom gates, permutation and lookup terms, folded with y) into ONE postfix program
-// whose instruction stream is wave-uniform (scalar loads / scalar branches) while the data path is
-// one row per lane: column reads are 32-B-per-lane contiguous, the operand stack lives in LDS with
-// the top of stack in registers.
+// numerator (custom gates, permutation and lookup terms, each with its power of y) into ONE postfix
+// program whose instruction stream is wave-uniform (scalar loads / scalar branches) while the data
+// path is one row per lane: column reads are 32-B-per-lane contiguous, the operand stack lives in LDS
+// with the top of stack in registers.
 #include <stdlib.h>
 #include <string.h>
 

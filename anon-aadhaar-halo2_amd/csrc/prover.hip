@@ -472,7 +472,7 @@ int emit_compressed(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, uint32_t first, u
 //     bounds would leave the reduction's range.
 // Bounds: a column, constant or hot value is below 1 (canonical); a product is below 2; a sum adds the bounds; a
 // difference a - b adds K to a's; the weak reduction gives 1.0002; a flushed group sum(bounds) / 169.3 + 1.
-// Returns the number of terms (= y powers the kernel needs, ExprArgs::ypow).
+// Returns the number of terms (= the powers of y of amdzk_pk::d_ypow that the OP_WACC instructions point at).
 uint32_t finalize_limb_program(Program& pr) {
   const double LIM = 160.0, RED = 1.01, GROUP_LIM = 169.0 * 30.0;  // a flushed group stays below ~31 p (+ h, canonical)
   struct Term {
