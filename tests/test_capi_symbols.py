@@ -51,3 +51,24 @@ def test_product_does_not_touch_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 for needle in ("oracle/", "liboracle", "pyref", "bn254_ref", "zkutil"):
                     assert needle not in text, "%s references %s" % (os.path.join(dirpath, f), needle)
+
+
+def test_library_load_sets_hw_queue_default_without_overriding():
+    """libamdzk.so raises the HIP runtime's hardware-queue count (GPU_MAX_HW_QUEUES, 4 by default) when it is loaded —
+    several proofs in flight need as many queues as contexts (profiles/r02j_hw_queues_sweep.txt) — and never overrides a
+    value the host has chosen. Checked in fresh interpreters (the variable is process state)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "anon-aadhaar-halo2_amd", "libamdzk.so")
+    # os.environ does not see setenv() done by C code: ask the C library
+    code = ("import ctypes; ctypes.CDLL(%r); libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; "
+            "print((libc.getenv(b'GPU_MAX_HW_QUEUES') or b'').decode())" % lib)
+    for preset, want in ((None, "16"), ("6", "6")):
+        env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+        if preset is not None:
+            env["GPU_MAX_HW_QUEUES"] = preset
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.strip() == want, (preset, out.stdout, out.stderr)
