@@ -199,6 +199,7 @@ struct amdzk_pk {
   Fr* ls() { return P + (size_t)(A + I + L) * n; }
   Fr* zp() { return P + (size_t)(A + I + 2 * L) * n; }
   Fr* zl() { return P + (size_t)(A + I + 2 * L + nsets) * n; }
+  Fr* rnd_lagrange() { return P + NP * n; }  // column NP: not one of the NP polynomials that go to the cosets
   // slots, Lagrange table
   uint32_t sl_fixed(uint32_t c) { return c; }
   uint32_t sl_adv(uint32_t c) { return F + c; }
@@ -869,7 +870,7 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
   KG_TRY(dalloc(ctx, pk, &pk->x_coset, ext));
   KG_TRY(dalloc(ctx, pk, &pk->omega_pow, n));
   pk->NP = (size_t)A + I + 2 * L + ns + L;
-  KG_TRY(dalloc(ctx, pk, &pk->P, pk->NP * n));
+  KG_TRY(dalloc(ctx, pk, &pk->P, (pk->NP + 1) * n));  // + the random polynomial's Lagrange values, committed with the product columns
   KG_TRY(dalloc(ctx, pk, &pk->PC, pk->NP * ext));
   KG_TRY(dalloc(ctx, pk, &pk->ci, (size_t)L * n));
   KG_TRY(dalloc(ctx, pk, &pk->ct, (size_t)L * n));
@@ -1500,9 +1501,6 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     }
     ZK_TRY(blind_rows(pk->zp(), ns, n - bf, bf, tail));
     tick("  perm: blind");
-    std::vector<G1Affine> cm;
-    ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G_LAGRANGE, pk->zp(), ns, cm));
-    ZK_TRY(write_points(cm, "perm_z"));
   }
   tick("perm_products");
   // 4. lookup grand products
@@ -1517,12 +1515,9 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
       (void)rng.fr();
     }
     ZK_TRY(blind_rows(pk->zl(), L, n - bf, bf, tail));
-    std::vector<G1Affine> cm;
-    ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G_LAGRANGE, pk->zl(), L, cm));
-    ZK_TRY(write_points(cm, "lookup_z"));
   }
   tick("lookup_products");
-  // 5. vanishing: random polynomial (coefficient form), commit with g
+  // 5. vanishing: the random polynomial (coefficient form). Its draws follow the blinding rows above, as upstream's do.
   {
     if (rng.rng && rng.rng->at_block_boundary()) {
       // ChaCha20Rng: draw j of the stream is key-stream block j, so the n coefficients come from one kernel
@@ -1536,9 +1531,21 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     }
     (void)rng.fr();
     tick("  random: rng");
+  }
+  // The lookup products depend on beta and gamma only, not on the permutation products' commitments, and the random
+  // polynomial on neither: ONE multi-scalar multiplication commits all three — the bucket folds of a batch are
+  // latency-bound launches, paid once instead of three times. The product columns are adjacent in the key's
+  // workspace; the random polynomial joins them as its Lagrange values (one more transform of size n): committing
+  // those with g_lagrange is committing its coefficients with g, the same group element. Written in upstream's order.
+  {
+    ZK_TRY(d2d(ctx, pk->rnd_lagrange(), pk->rnd, n * 32));
+    ZK_TRY(amdzk_coeff_to_lagrange_dev(ctx, pk->dom, pk->rnd_lagrange(), 1, n));
     std::vector<G1Affine> cm;
-    ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G, pk->rnd, 1, cm));
-    ZK_TRY(write_points(cm, "random_poly"));
+    ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G_LAGRANGE, pk->zp(), ns + L + 1, cm));
+    std::vector<G1Affine> pz(cm.begin(), cm.begin() + ns), lz(cm.begin() + ns, cm.begin() + ns + L), rz(cm.begin() + ns + L, cm.end());
+    ZK_TRY(write_points(pz, "perm_z"));
+    ZK_TRY(write_points(lz, "lookup_z"));
+    ZK_TRY(write_points(rz, "random_poly"));
   }
   tick("random_poly");
   Fr y = T.squeeze_challenge();
