@@ -107,6 +107,30 @@ def test_quotient_coset_modes(ctx, pkg, plonk, oracle, monkeypatch):
             PR.verify_proof(opk, bad.instances, proofs[(mode, "bad")])
 
 
+def test_merged_commitments_mode_gives_the_same_bytes(ctx, pkg, plonk, oracle, monkeypatch):
+    """AMDZK_MERGE_COMMITS=1 (read at keygen): the permutation products, the lookup products and the random polynomial —
+    the latter as its Lagrange values under g_lagrange instead of its coefficients under g — are committed by one
+    multi-scalar multiplication. Same group elements, same transcript order: the proof bytes must not change
+    (SHPLONK and GWC, a circuit with lookups and one without)."""
+    shapes = [circuits.rsa_sha256_shape(plonk, k=7, num_advice=5, num_lookup_advice=2, lookup_bits=5, num_spread=2, spread_bits=3),
+              circuits.lookup_circuit(plonk, 6, seed=9)]
+    for c in shapes:
+        got = {}
+        for mode in ("split", "merged"):
+            if mode == "merged":
+                monkeypatch.setenv("AMDZK_MERGE_COMMITS", "1")
+            else:
+                monkeypatch.delenv("AMDZK_MERGE_COMMITS", raising=False)
+            params, pk, d_adv, inst = setup(ctx, pkg, plonk, oracle, c)
+            got[mode] = [plonk.create_proof(ctx, pk, inst, d_adv, seed=33),
+                         plonk.create_proof(ctx, pk, inst, d_adv, seed=34, transcript=plonk.MULTIOPEN_GWC)]
+            d_adv.free(); pk.free(); params.free()
+        monkeypatch.delenv("AMDZK_MERGE_COMMITS", raising=False)
+        assert got["split"] == got["merged"]
+        opk = PR.keygen(c.desc, c.fixed, c.assembly.mapping, TAU, transcript_repr=123456789)
+        assert got["merged"][0] == PR.create_proof(opk, c.instances, c.advice, seed=33)
+
+
 def test_lookup_failure_is_reported(ctx, pkg, plonk, oracle):
     c = circuits.lookup_circuit(plonk, 5, seed=4)
     rows = [r for r in range(c.usable) if c.fixed[2][r] == 1]  # fixed[2] = q_rng: range lookup enabled

@@ -9,7 +9,7 @@ cp $LIB /tmp/libamdzk_keep.so
 for round in 1 2 3; do
   for v in old new; do
     cp ab/libamdzk_$v.so $LIB
-    timeout -k 10 200 python bench.py --steps 40 --warmup 4 --no-cpu-baseline ${AB_FLAGS:-} 2>/dev/null | tail -1 > gpurun_out/ab_${v}_$round.json || exit 1
+    timeout -k 10 200 python bench.py --steps 48 --warmup 4 --no-cpu-baseline ${AB_FLAGS:-} 2>/dev/null | tail -1 > gpurun_out/ab_${v}_$round.json || exit 1
     python - "$v" "$round" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/ab_%s_%s.json" % (sys.argv[1], sys.argv[2])))
