@@ -60,6 +60,8 @@ def parse_args(argv=None):
                          "one of 5, 4, 3, else 8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stream-pass", action="store_true", help="skip the PCIe-inclusive pass (one witness upload per proof)")
+    ap.add_argument("--no-merged-latency", action="store_true",
+                    help="skip the single-proof latency in the key's merged-commitments mode (one more keygen and two proofs; tools/profile_gpu.sh)")
     return ap.parse_args(argv)
 
 
@@ -428,7 +430,7 @@ def run_rank(args):
         t_l = time.perf_counter()
         ref = prover.prove(0, 0, 777001)
         lat_ms = (time.perf_counter() - t_l) * 1e3
-        lat_merged_ms = prover.latency_with_merged_commitments(ref, 777001)
+        lat_merged_ms = None if args.no_merged_latency else prover.latency_with_merged_commitments(ref, 777001)
         if not args.no_cpu_baseline:
             gpu_proof = prover.prove(0, 0, 424242)
             cpu = cpu_baseline(prover, gpu_proof)

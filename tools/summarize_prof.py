@@ -67,7 +67,7 @@ def mad_share_of_hot_loop():
 
 def main():
     src, tag = sys.argv[1], sys.argv[2]
-    proofs = float(sys.argv[3]) if len(sys.argv) > 3 else 3.0  # warm-up + timed + the profiled extra proof of bench.py
+    proofs = float(sys.argv[3]) if len(sys.argv) > 3 else 4.0  # warm-up + timed + the per-kernel-timed proof + the latency proof of bench.py
     os.makedirs("profiles", exist_ok=True)
     stats = collections.OrderedDict()
     c = db(src, "stats")
@@ -99,6 +99,20 @@ def main():
                     agg[k][0] += 1
                     agg[k][1] += float(val)
         pmc[kind] = agg
+    # ONE proof in the steady state = the dispatches between the last two random-polynomial kernels (one per proof):
+    # totals over the whole run also hold keygen's commitments and transforms, which are not per-proof work
+    one_proof = None
+    c = db(src, "insts")
+    if c:
+        seq = c.execute("select dispatch_id, name, sum(counter_value) from pmc_events where counter_name = 'SQ_INSTS_VALU' "
+                        "group by dispatch_id, name order by dispatch_id").fetchall()
+        marks = [d for d, name, _ in seq if "chacha20_fr_random" in name]
+        if len(marks) >= 2:
+            a, b = marks[-2], marks[-1]
+            one_proof = collections.Counter()
+            for d, name, v in seq:
+                if a < d <= b:
+                    one_proof[short(name)] += v
     import bench
     path = os.path.join("profiles", tag + "_kernel_summary.csv")
     with open(path, "w") as o:
@@ -121,15 +135,20 @@ def main():
         per_proof = sum(v.get("SQ_INSTS_VALU", 0) for k, v in per_counter.items() if k not in STARTUP)
         with open(os.path.join("profiles", tag + "_valu_instruction_counts.txt"), "w") as o:
             o.write("rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES -- python3 bench.py --steps 1 --warmup 1 "
-                    "--concurrency 1 --no-cpu-baseline --no-stream-pass\n(shape full, k = 15, kernel sources %s; keygen + %.2f proofs)\n\n" % (bench.kernel_src_hash(), proofs))
+                    "--concurrency 1 --no-cpu-baseline --no-stream-pass --no-merged-latency\n(shape full, k = 15, kernel sources %s; keygen + %.2f proofs)\n\n" % (bench.kernel_src_hash(), proofs))
             o.write("%-46s %6s %12s %10s %10s %10s %10s\n" % ("kernel", "calls", "VALU", "SALU", "LDS", "VMEM_RD", "waves"))
             for k, v in sorted(per_counter.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0))[:24]:
                 o.write("%-46s %6d %12.3e %10.2e %10.2e %10.2e %10.2e%s\n" % (k[:46], calls_insts[k], v.get("SQ_INSTS_VALU", 0), v.get("SQ_INSTS_SALU", 0),
                                                                       v.get("SQ_INSTS_LDS", 0), v.get("SQ_INSTS_VMEM_RD", 0), v.get("SQ_WAVES", 0),
                                                                       "   (start-up)" if k in STARTUP else ""))
-            o.write("\nVALU wave-instructions outside the start-up kernels: %.3e over %.2f proofs = %.3e per proof\n" % (per_proof, proofs, per_proof / proofs))
-            for cpi in (4.0, 4.5, 5.0):
-                o.write("  at %.1f cycles per VALU wave-instruction on 1024 SIMDs at 2.4 GHz: %.1f ms per proof\n" % (cpi, per_proof / proofs * cpi / (1024 * 2.4e9) * 1e3))
+            o.write("\nVALU wave-instructions outside the start-up kernels: %.3e over keygen + %.2f proofs\n" % (per_proof, proofs))
+            if one_proof:
+                tot = sum(one_proof.values())
+                o.write("\nONE proof (the dispatches between the last two random-polynomial kernels): %.3e VALU wave-instructions\n" % tot)
+                for k, v in one_proof.most_common(12):
+                    o.write("  %-44s %10.3e  %5.1f %%\n" % (k[:44], v, 100.0 * v / tot))
+                for cpi in (4.0, 4.5, 5.0):
+                    o.write("  at %.1f cycles per VALU wave-instruction on 1024 SIMDs at 2.4 GHz: %.1f ms per proof\n" % (cpi, tot * cpi / (1024 * 2.4e9) * 1e3))
         print(open(os.path.join("profiles", tag + "_valu_instruction_counts.txt")).read())
 
 
