@@ -592,7 +592,7 @@ def pmc_counters(kernel):
 
 
 def cpu_baseline(prover, gpu_proof):
-    """CPU leg: ONE full create_proof of the same circuit, witness, SRS and RNG seed on the host cores with the oracle
+    """CPU leg: full create_proof runs of the same circuit, witness, SRS and RNG seed on the host cores with the oracle
     prover (oracle/plonk_fast.py: upstream's step order; every O(n) loop — Pippenger MSM per commitment as halo2's
     best_multiexp, radix-2 FFTs, the h(X) evaluation, permutation / lookup products, evaluations — in the C++ oracle under
     OpenMP; transcript, RNG and glue in Python, which inflates the CPU time somewhat). Its proof must equal the GPU's byte
@@ -606,13 +606,17 @@ def cpu_baseline(prover, gpu_proof):
     t0 = time.perf_counter()
     fpk = PF.FastKey(c.desc, c.fixed, c.assembly.mapping, prover.s_int, prover.tr_int, msm_bases=(prover.params._g, prover.params._gl))
     t_keygen = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    proof = PF.create_proof(fpk, instances, advice, seed=424242)
-    dt = time.perf_counter() - t0
+    times, equal = [], True
+    for _ in range(2):  # two samples (~17 s of CPU work on the box's 16 threads): the first also warms the OpenMP pool
+        t0 = time.perf_counter()
+        proof = PF.create_proof(fpk, instances, advice, seed=424242)
+        times.append(time.perf_counter() - t0)
+        equal = equal and proof == gpu_proof
+    dt = min(times)
     return {"value": round(1.0 / dt, 5), "unit": "proofs/s", "cores": PF.threads(), "kind": "port",
-            "sample": "1 full create_proof (same circuit/witness/SRS/seed as the GPU run) with the C++/OpenMP oracle prover, "
-                      "%d threads; Python transcript/RNG/glue included; keygen (%.0f s) excluded" % (PF.threads(), t_keygen),
-            "seconds_per_proof": round(dt, 2), "proof_bytes_equal_gpu": proof == gpu_proof}
+            "sample": "2 full create_proof runs (same circuit/witness/SRS/seed as the GPU run) with the C++/OpenMP oracle prover, "
+                      "%d threads, the faster one reported; Python transcript/RNG/glue included; keygen (%.0f s) excluded" % (PF.threads(), t_keygen),
+            "seconds_per_proof": round(dt, 2), "seconds_per_proof_samples": [round(t, 2) for t in times], "proof_bytes_equal_gpu": equal}
 
 
 def main(argv=None):
