@@ -111,9 +111,9 @@ def test_merged_commitments_mode_gives_the_same_bytes(ctx, pkg, plonk, oracle, m
     """AMDZK_MERGE_COMMITS=1 (read at keygen): the permutation products, the lookup products and the random polynomial —
     the latter as its Lagrange values under g_lagrange instead of its coefficients under g — are committed by one
     multi-scalar multiplication. Same group elements, same transcript order: the proof bytes must not change
-    (SHPLONK and GWC, a circuit with lookups and one without)."""
+    (SHPLONK and GWC; circuits with lookups and permutations, and the reference's SquareCircuit with neither lookups nor a second permutation set)."""
     shapes = [circuits.rsa_sha256_shape(plonk, k=7, num_advice=5, num_lookup_advice=2, lookup_bits=5, num_spread=2, spread_bits=3),
-              circuits.lookup_circuit(plonk, 6, seed=9)]
+              circuits.lookup_circuit(plonk, 6, seed=9), circuits.square_circuit(plonk, 4, signal=5)]
     for c in shapes:
         got = {}
         for mode in ("split", "merged"):
