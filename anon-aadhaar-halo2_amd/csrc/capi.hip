@@ -102,6 +102,66 @@ int zk_ptr_on_device(amdzk_ctx* ctx, const void* p, const char* what) {
   return AMDZK_OK;
 }
 
+int zk_lane(amdzk_ctx* ctx, int i, amdzk_ctx** out) {
+  if (i < 0 || i >= amdzk_ctx::MAX_LANES) ZK_FAIL(ctx, AMDZK_E_INVALID, "lane %d out of range", i);
+  if (ctx->prof || ctx->parent) {  // profiling: one stream; a lane has no lanes of its own
+    *out = ctx;
+    return AMDZK_OK;
+  }
+  if (!ctx->lanes[i]) {
+    amdzk_ctx* l = new amdzk_ctx();
+    l->device = ctx->device;
+    l->num_cu = ctx->num_cu;
+    l->parent = ctx;
+    if (hipStreamCreateWithFlags(&l->own_stream, hipStreamNonBlocking) != hipSuccess) {
+      delete l;
+      ZK_FAIL(ctx, AMDZK_E_HIP, "lane %d: hipStreamCreate failed", i);
+    }
+    l->stream = l->own_stream;
+    ctx->lanes[i] = l;
+  }
+  *out = ctx->lanes[i];
+  return AMDZK_OK;
+}
+
+int zk_stream_after(amdzk_ctx* waiter, amdzk_ctx* signaler) {
+  if (waiter == signaler || waiter->stream == signaler->stream) return AMDZK_OK;
+  hipEvent_t& e = signaler->order_evt[signaler->order_next++ % 8];
+  if (!e) ZK_HIP(waiter, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  ZK_HIP(waiter, hipEventRecord(e, signaler->stream));
+  ZK_HIP(waiter, hipStreamWaitEvent(waiter->stream, e, 0));
+  return AMDZK_OK;
+}
+
+int zk_sync_all(amdzk_ctx* ctx) {
+  amdzk_ctx* root = ctx->parent ? ctx->parent : ctx;
+  ZK_HIP(ctx, hipStreamSynchronize(root->stream));
+  for (amdzk_ctx* l : root->lanes)
+    if (l) ZK_HIP(ctx, hipStreamSynchronize(l->stream));
+  return AMDZK_OK;
+}
+
+static void ctx_release(amdzk_ctx* ctx) {
+  hipStreamSynchronize(ctx->stream);
+  zk_prof_drain(ctx);
+  for (auto& kv : ctx->twiddles) hipFree(kv.second);
+  for (auto& w : ctx->ws)
+    if (w.p) hipFree(w.p);
+  if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+  for (auto e : ctx->evt_pool) hipEventDestroy(e);
+  for (auto e : ctx->order_evt)
+    if (e) hipEventDestroy(e);
+  if (ctx->t0) hipEventDestroy(ctx->t0);
+  if (ctx->t1) hipEventDestroy(ctx->t1);
+  if (ctx->copy_stream) {
+    hipStreamSynchronize(ctx->copy_stream);
+    hipStreamDestroy(ctx->copy_stream);
+  }
+  if (ctx->copy_evt) hipEventDestroy(ctx->copy_evt);
+  if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
 // One context = one HIP stream, and a host that keeps several proofs in flight uses several contexts. The HIP runtime
 // maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues, 4 unless the environment says otherwise, and kernels
 // of streams that share a queue wait for each other: 8 proofs in flight on 4 queues measure no better than 4
@@ -148,22 +208,12 @@ int amdzk_init(int device_id, amdzk_ctx** out) {
 void amdzk_destroy(amdzk_ctx* ctx) {
   ZK_ENTER(ctx);
   if (!ctx) return;
-  hipStreamSynchronize(ctx->stream);
-  zk_prof_drain(ctx);
-  for (auto& kv : ctx->twiddles) hipFree(kv.second);
-  for (auto& w : ctx->ws)
-    if (w.p) hipFree(w.p);
-  if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
-  for (auto e : ctx->evt_pool) hipEventDestroy(e);
-  if (ctx->t0) hipEventDestroy(ctx->t0);
-  if (ctx->t1) hipEventDestroy(ctx->t1);
-  if (ctx->copy_stream) {
-    hipStreamSynchronize(ctx->copy_stream);
-    hipStreamDestroy(ctx->copy_stream);
-  }
-  if (ctx->copy_evt) hipEventDestroy(ctx->copy_evt);
-  if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
-  delete ctx;
+  for (amdzk_ctx*& l : ctx->lanes)
+    if (l) {
+      ctx_release(l);
+      l = nullptr;
+    }
+  ctx_release(ctx);
 }
 
 const char* amdzk_last_error(const amdzk_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -179,8 +229,7 @@ int amdzk_set_stream(amdzk_ctx* ctx, void* hip_stream) {
 int amdzk_sync(amdzk_ctx* ctx) {
   ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return AMDZK_OK;
+  return zk_sync_all(ctx);
 }
 
 int amdzk_dev_alloc(amdzk_ctx* ctx, size_t bytes, void** dptr) {
@@ -377,6 +426,13 @@ int amdzk_ctx_check_affinity(amdzk_ctx* ctx) {
   if (dev != ctx->device) ZK_FAIL(ctx, AMDZK_E_INVALID, "affinity: stream is on device %d, ctx on %d", dev, ctx->device);
   for (int i = 0; i < 8; i++) ZK_TRY(zk_ptr_on_device(ctx, ctx->ws[i].p, "workspace"));
   for (auto& kv : ctx->twiddles) ZK_TRY(zk_ptr_on_device(ctx, kv.second, "twiddle table"));
+  for (amdzk_ctx* l : ctx->lanes)
+    if (l) {
+      ZK_HIP(ctx, hipStreamGetDevice(l->stream, &dev));
+      if (dev != ctx->device) ZK_FAIL(ctx, AMDZK_E_INVALID, "affinity: a lane's stream is on device %d, ctx on %d", dev, ctx->device);
+      for (int i = 0; i < 8; i++) ZK_TRY(zk_ptr_on_device(ctx, l->ws[i].p, "lane workspace"));
+      for (auto& kv : l->twiddles) ZK_TRY(zk_ptr_on_device(ctx, kv.second, "lane twiddle table"));
+    }
   return AMDZK_OK;
 }
 int amdzk_ptr_check_affinity(amdzk_ctx* ctx, const void* dptr) {

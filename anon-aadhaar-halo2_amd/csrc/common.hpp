@@ -62,6 +62,16 @@ struct amdzk_ctx {
   // pinned host staging for small results
   void* h_pinned = nullptr;
   size_t h_pinned_cap = 0;
+
+  // Lanes: auxiliary contexts on the same device (own stream, workspaces, staging) for work of ONE call that is
+  // independent of what the call's main stream is doing — create_proof puts the coset transforms of a phase's columns,
+  // the lookup products and the random polynomial beside the commitments the transcript is waiting for. Created on
+  // first use (zk_lane), ordered against each other with events only (zk_stream_after), freed with the ctx.
+  static constexpr int MAX_LANES = 2;
+  amdzk_ctx* lanes[MAX_LANES] = {nullptr, nullptr};
+  amdzk_ctx* parent = nullptr;
+  hipEvent_t order_evt[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  unsigned order_next = 0;
 };
 
 #define ZK_FAIL(ctx, code, ...)                         \
@@ -115,6 +125,14 @@ int zk_ws_reserve(amdzk_ctx* ctx, int slot, size_t bytes, void** out);
 int zk_pinned_reserve(amdzk_ctx* ctx, size_t bytes, void** out);
 int zk_ptr_on_device(amdzk_ctx* ctx, const void* p, const char* what);
 hipEvent_t zk_evt_get(amdzk_ctx* ctx);
+// Lane i of ctx (created on first use). While per-kernel profiling is on, a lane IS the ctx: one stream, so that the
+// event-bracketed kernel times are those of kernels running alone.
+int zk_lane(amdzk_ctx* ctx, int i, amdzk_ctx** out);
+// Everything enqueued on `waiter`'s stream after this call runs after everything enqueued on `signaler`'s stream
+// before it (event record + stream wait; no host synchronisation). No-op when both are the same context.
+int zk_stream_after(amdzk_ctx* waiter, amdzk_ctx* signaler);
+// Host waits for the ctx's stream and all its lanes.
+int zk_sync_all(amdzk_ctx* ctx);
 void zk_prof_drain(amdzk_ctx* ctx);
 
 // Launch wrapper: kernel<<<grid, block, shmem, ctx->stream>>>(args...), optionally event-bracketed.

@@ -609,19 +609,29 @@ __global__ void sub_low_kernel(Fr* a, const Fr* low, uint32_t m) {
 // grid = (blocks per polynomial, polynomials).
 constexpr uint32_t KD_THREADS = 256, KD_E = 8, KD_BLOCK = KD_THREADS * KD_E;
 
+// The dividend of polynomial `poly` is srcs[poly] (polys[poly] itself when srcs is null) minus the low-degree
+// polynomial lows[poly * low_stride ..] (low_stride coefficients, zero padded; none when lows is null) — the copy and
+// the subtraction SHPLONK needs before each of its divisions ride in on the loads.
 template <bool WRITE>
 __global__ __launch_bounds__(KD_THREADS) void kate_div_kernel(Fr* const* polys, const Fr* roots, uint32_t n, uint32_t nblk, Fr* totals,
-                                                              const Fr* carries) {
+                                                              const Fr* carries, const Fr* const* srcs, const Fr* lows, uint32_t low_stride) {
   __shared__ Fr S[KD_THREADS];
   const uint32_t t = threadIdx.x, blk = blockIdx.x, poly = blockIdx.y;
   Fr* a = polys[poly];
+  const Fr* src = srcs ? srcs[poly] : a;
+  const Fr* low = lows ? lows + (size_t)poly * low_stride : nullptr;
+  auto ld_src = [&](uint32_t j) -> Fr {
+    Fr v = ld_fr(src + j);
+    if (low && j < low_stride) v = sub(v, ld_fr(low + j));
+    return v;
+  };
   const Fr b = ld_fr(roots + poly);
   const Fr br = fr29_const_to_r261(b);  // the root in radix 2^261: the chunk recurrences are data x constant
   const uint32_t s = blk * KD_BLOCK + t * KD_E, e = min(s + KD_E, n);
   Fr acc = Fr::zero();
   if (s < n) {
-    acc = ld_fr(a + e - 1);
-    for (uint32_t j = e - 1; j-- > s;) acc = add(fr29_mul_const(acc, br), ld_fr(a + j));
+    acc = ld_src(e - 1);
+    for (uint32_t j = e - 1; j-- > s;) acc = add(fr29_mul_const(acc, br), ld_src(j));
   }
   S[t] = acc;  // chunk value relative to its own start
   __syncthreads();
@@ -642,7 +652,7 @@ __global__ __launch_bounds__(KD_THREADS) void kate_div_kernel(Fr* const* polys, 
     Fr prev = t + 1 < KD_THREADS ? S[t + 1] : Fr::zero();
     if (carries) prev = add(prev, mul(pow_u64(b, (uint64_t)KD_E * (KD_THREADS - 1 - t)), ld_fr(carries + (size_t)poly * nblk + blk)));
     for (uint32_t j = e; j-- > s;) {
-      Fr aj = ld_fr(a + j);
+      Fr aj = ld_src(j);
       st_fr(a + j, prev);
       prev = add(aj, fr29_mul_const(prev, br));
     }
@@ -897,21 +907,31 @@ int zk_sub_low(amdzk_ctx* ctx, Fr* d_a, const Fr* d_low, uint32_t m) {
 }
 
 int zk_kate_div(amdzk_ctx* ctx, Fr* const* d_polys, const Fr* d_roots, size_t npolys, uint32_t n) {
+  return zk_kate_div_from(ctx, d_polys, nullptr, d_roots, nullptr, 0, npolys, n);
+}
+
+// d_polys[i] = (d_srcs[i] - low_i) / (X - root_i), low_i = d_lows[i * low_stride ..] (low_stride coefficients each; null: none).
+// d_srcs null: in place. A source may feed several quotients; a source must not be one of the OTHER destinations.
+int zk_kate_div_from(amdzk_ctx* ctx, Fr* const* d_polys, const Fr* const* d_srcs, const Fr* d_roots, const Fr* d_lows, uint32_t low_stride,
+                     size_t npolys, uint32_t n) {
   if (npolys == 0 || n == 0) return AMDZK_OK;
   const uint32_t nblk = (n + KD_BLOCK - 1) / KD_BLOCK;
   dim3 grid(nblk, (unsigned)npolys), block(KD_THREADS);
   if (nblk == 1) {
-    ZK_LAUNCH(ctx, "kate_div", kate_div_kernel<true>, grid, block, 0, d_polys, d_roots, n, nblk, (Fr*)nullptr, (const Fr*)nullptr);
+    ZK_LAUNCH(ctx, "kate_div", kate_div_kernel<true>, grid, block, 0, d_polys, d_roots, n, nblk, (Fr*)nullptr, (const Fr*)nullptr, d_srcs, d_lows,
+              low_stride);
     return AMDZK_OK;
   }
   Fr* tmp = nullptr;  // totals | carries
   ZK_TRY(zk_ws_reserve(ctx, 4, 2 * npolys * nblk * sizeof(Fr), (void**)&tmp));
   Fr* totals = tmp;
   Fr* carries = tmp + npolys * nblk;
-  ZK_LAUNCH(ctx, "kate_div_totals", kate_div_kernel<false>, grid, block, 0, d_polys, d_roots, n, nblk, totals, (const Fr*)nullptr);
+  ZK_LAUNCH(ctx, "kate_div_totals", kate_div_kernel<false>, grid, block, 0, d_polys, d_roots, n, nblk, totals, (const Fr*)nullptr, d_srcs, d_lows,
+            low_stride);
   ZK_LAUNCH(ctx, "kate_div_carry", kate_carry_kernel, dim3((unsigned)((npolys + 63) / 64)), dim3(64), 0, totals, carries, d_roots, nblk,
             (uint32_t)npolys);
-  ZK_LAUNCH(ctx, "kate_div", kate_div_kernel<true>, grid, block, 0, d_polys, d_roots, n, nblk, (Fr*)nullptr, (const Fr*)carries);
+  ZK_LAUNCH(ctx, "kate_div", kate_div_kernel<true>, grid, block, 0, d_polys, d_roots, n, nblk, (Fr*)nullptr, (const Fr*)carries, d_srcs, d_lows,
+            low_stride);
   return AMDZK_OK;
 }
 

@@ -82,6 +82,8 @@ int zk_lincomb(amdzk_ctx* ctx, const bn254::Fr* const* d_polys, const bn254::Fr*
 int zk_scale(amdzk_ctx* ctx, bn254::Fr* d_a, size_t n, const bn254::Fr& c);
 int zk_sub_low(amdzk_ctx* ctx, bn254::Fr* d_a, const bn254::Fr* d_low, uint32_t m);
 int zk_kate_div(amdzk_ctx* ctx, bn254::Fr* const* d_polys, const bn254::Fr* d_roots, size_t npolys, uint32_t n);
+int zk_kate_div_from(amdzk_ctx* ctx, bn254::Fr* const* d_polys, const bn254::Fr* const* d_srcs, const bn254::Fr* d_roots, const bn254::Fr* d_lows,
+                     uint32_t low_stride, size_t npolys, uint32_t n);
 int zk_scatter_rows(amdzk_ctx* ctx, bn254::Fr* d_dst, size_t col_stride, size_t row0, const bn254::Fr* d_src, uint32_t cnt,
                     uint32_t ncols);
 int zk_sort_keys(amdzk_ctx* ctx, bn254::Fr* d_cols, size_t ncols, uint32_t n, size_t col_stride);

@@ -35,6 +35,7 @@ struct amdzk_domain {
   Fr* d_coset_out = nullptr;   // [nc][n]  g_c^-m / (32 * n * (g_c^n - 1))         (radix 2^261 constants)
   std::vector<Fr> coset_g;     // g_c
   std::vector<Fr> vinv;        // [nc][nc] inverse of V[c][j] = (g_c^n)^j, row-major [j][c]
+  Fr* d_vinv261 = nullptr;     // the same as radix-2^261 constants, on the device (coset_combine's weights)
 };
 
 namespace {
@@ -96,19 +97,31 @@ __global__ void coset_table_kernel(Fr* tab, Fr g, Fr scale, uint32_t count, uint
   }
 }
 
-// out[j][m] = sum_c w[j][c] * d[c][m], j < nout, c < nc (nc <= 8): the pieces of h(X) from its per-coset
-// interpolants. w: radix-2^261 constants, row-major [j][c].
-struct CombineW {
-  Fr w[64];
-};
-__global__ __launch_bounds__(256) void coset_combine_kernel(const Fr* d, Fr* out, uint32_t n, uint32_t nc, uint32_t nout, CombineW cw) {
+// out[j][m] = sum_c w[j][c] * d[c][m], j < nout <= nc: the pieces of h(X) from its per-coset interpolants.
+// w: radix-2^261 constants, row-major [j][c], in device memory. Templated on nc (1..8: the loops unroll completely, so
+// the per-coset values live in registers — no dynamically indexed per-thread array next to inlined products, the shape
+// DESIGN.md §6 records as miscompiled at -O3); more cosets (constraint degree above 9) take the generic kernel, which
+// re-reads d[c][m] per output instead of keeping an array.
+template <int NC>
+__global__ __launch_bounds__(256) void coset_combine_kernel(const Fr* d, Fr* out, uint32_t n, uint32_t nout, const Fr* w) {
   const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= n) return;
-  Fr v[8];
-  for (uint32_t c = 0; c < nc; c++) v[c] = ld_fr(d + (size_t)c * n + m);
+  Fr v[NC];
+#pragma unroll
+  for (int c = 0; c < NC; c++) v[c] = ld_fr(d + (size_t)c * n + m);
   for (uint32_t j = 0; j < nout; j++) {
-    Fr acc = fr29_mul_const(v[0], cw.w[j * nc]);
-    for (uint32_t c = 1; c < nc; c++) acc = add(acc, fr29_mul_const(v[c], cw.w[j * nc + c]));
+    Fr acc = fr29_mul_const(v[0], ld_fr(w + (size_t)j * NC));
+#pragma unroll
+    for (int c = 1; c < NC; c++) acc = add(acc, fr29_mul_const(v[c], ld_fr(w + (size_t)j * NC + c)));
+    st_fr(out + (size_t)j * n + m, acc);
+  }
+}
+__global__ __launch_bounds__(256) void coset_combine_generic_kernel(const Fr* d, Fr* out, uint32_t n, uint32_t nc, uint32_t nout, const Fr* w) {
+  const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n) return;
+  for (uint32_t j = 0; j < nout; j++) {
+    Fr acc = fr29_mul_const(ld_fr(d + m), ld_fr(w + (size_t)j * nc));
+    for (uint32_t c = 1; c < nc; c++) acc = add(acc, fr29_mul_const(ld_fr(d + (size_t)c * n + m), ld_fr(w + (size_t)j * nc + c)));
     st_fr(out + (size_t)j * n + m, acc);
   }
 }
@@ -192,6 +205,7 @@ void amdzk_domain_free(amdzk_ctx* ctx, amdzk_domain* d) {
   if (d->d_t_evaluations) hipFree(d->d_t_evaluations);
   if (d->d_coset_in) hipFree(d->d_coset_in);
   if (d->d_coset_out) hipFree(d->d_coset_out);
+  if (d->d_vinv261) hipFree(d->d_vinv261);
   delete d;
 }
 
@@ -214,6 +228,14 @@ int amdzk_lagrange_to_coeff_dev(amdzk_ctx* ctx, const amdzk_domain* d, void* d_c
   Fr oc[3] = {d->ifft_divisor, d->ifft_divisor, d->ifft_divisor};
   return zk_ntt_ex(ctx, (Fr*)d_cols, col_stride, (Fr*)d_cols, col_stride, d->k, (const uint64_t*)d->omega_inv.l, ncols, 0, nullptr, oc, nullptr, nullptr);
 }
+
+}  // extern "C"
+// lagrange_to_coeff out of place (prover-private): the Lagrange values stay where they are
+int zk_lagrange_to_coeff(amdzk_ctx* ctx, const amdzk_domain* d, const Fr* d_in, size_t in_stride, Fr* d_out, size_t out_stride, size_t ncols) {
+  Fr oc[3] = {d->ifft_divisor, d->ifft_divisor, d->ifft_divisor};
+  return zk_ntt_ex(ctx, d_in, in_stride, d_out, out_stride, d->k, (const uint64_t*)d->omega_inv.l, ncols, 0, nullptr, oc, nullptr, nullptr);
+}
+extern "C" {
 
 int amdzk_coeff_to_lagrange_dev(amdzk_ctx* ctx, const amdzk_domain* d, void* d_cols, size_t ncols, size_t col_stride) {
   ZK_ENTER(ctx);
@@ -241,12 +263,13 @@ int amdzk_coeff_to_extended_dev(amdzk_ctx* ctx, const amdzk_domain* d, const voi
 int zk_quotient_plan(amdzk_ctx* ctx, amdzk_domain* d, uint32_t nc) {
   const uint32_t ncosets = 1u << (d->extended_k - d->k);
   if (nc == 0 || nc > ncosets) ZK_FAIL(ctx, AMDZK_E_INVALID, "quotient plan: %u cosets requested, the extended domain has %u", nc, ncosets);
-  if (nc > 8) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "quotient plan: more than 8 cosets (constraint degree above 9)");
+  if (nc > 64) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "quotient plan: more than 64 cosets (constraint degree above 65)");
   if (d->nc == nc) return AMDZK_OK;
   const size_t n = (size_t)1 << d->k;
   if (d->d_coset_in) ZK_HIP(ctx, hipFree(d->d_coset_in));
   if (d->d_coset_out) ZK_HIP(ctx, hipFree(d->d_coset_out));
-  d->d_coset_in = d->d_coset_out = nullptr;
+  if (d->d_vinv261) ZK_HIP(ctx, hipFree(d->d_vinv261));
+  d->d_coset_in = d->d_coset_out = d->d_vinv261 = nullptr;
   d->nc = 0;
   ZK_HIP(ctx, hipMalloc((void**)&d->d_coset_in, (size_t)nc * n * sizeof(Fr)));
   ZK_HIP(ctx, hipMalloc((void**)&d->d_coset_out, (size_t)nc * n * sizeof(Fr)));
@@ -266,7 +289,7 @@ int zk_quotient_plan(amdzk_ctx* ctx, amdzk_domain* d, uint32_t nc) {
     ZK_LAUNCH(ctx, "coset_table", coset_table_kernel, grid, block, 0, d->d_coset_in + (size_t)c * n, g, k32, (uint32_t)n, chunk);
     ZK_LAUNCH(ctx, "coset_table", coset_table_kernel, grid, block, 0, d->d_coset_out + (size_t)c * n, inv(g), mul(base, inv(den)), (uint32_t)n, chunk);
   }
-  // vinv = V^-1 with V[c][t] = gamma_c^t (Gauss-Jordan on the host; nc <= 8)
+  // vinv = V^-1 with V[c][t] = gamma_c^t (Gauss-Jordan on the host; nc is small)
   std::vector<Fr> a((size_t)nc * 2 * nc, Fr::zero());
   for (uint32_t c = 0; c < nc; c++) {
     Fr p = Fr::one();
@@ -294,6 +317,13 @@ int zk_quotient_plan(amdzk_ctx* ctx, amdzk_domain* d, uint32_t nc) {
   d->vinv.assign((size_t)nc * nc, Fr::zero());
   for (uint32_t t = 0; t < nc; t++)
     for (uint32_t c = 0; c < nc; c++) d->vinv[(size_t)t * nc + c] = a[(size_t)t * 2 * nc + nc + c];
+  {
+    std::vector<Fr> w(d->vinv.size());
+    for (size_t i = 0; i < w.size(); i++) w[i] = fr29_const_to_r261(d->vinv[i]);
+    ZK_HIP(ctx, hipMalloc((void**)&d->d_vinv261, w.size() * sizeof(Fr)));
+    ZK_HIP(ctx, hipMemcpyAsync(d->d_vinv261, w.data(), w.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
+    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `w` is a host temporary
+  }
   ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   d->nc = nc;
   return AMDZK_OK;
@@ -326,13 +356,18 @@ int zk_cosets_to_pieces(amdzk_ctx* ctx, const amdzk_domain* d, Fr* d_h, Fr* d_pi
   t.out_tab = d->d_coset_out;
   t.tab_col_stride = n;
   ZK_TRY(zk_ntt_ex(ctx, d_h, n, d_h, n, d->k, (const uint64_t*)d->omega_inv.l, d->nc, 0, nullptr, nullptr, nullptr, &t));
-  CombineW cw;
-  for (uint32_t j = 0; j < npieces; j++)
-    for (uint32_t c = 0; c < d->nc; c++) {
-      cw.w[j * d->nc + c] = fr29_const_to_r261(d->vinv[(size_t)j * d->nc + c]);
-    }
-  ZK_LAUNCH(ctx, "coset_combine", coset_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (const Fr*)d_h, d_pieces, (uint32_t)n,
-            d->nc, npieces, cw);
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+#define COMBINE(NC)                                                                                                                     \
+  case NC:                                                                                                                              \
+    ZK_LAUNCH(ctx, "coset_combine", coset_combine_kernel<NC>, grid, block, 0, (const Fr*)d_h, d_pieces, (uint32_t)n, npieces, (const Fr*)d->d_vinv261); \
+    break;
+  switch (d->nc) {
+    COMBINE(1) COMBINE(2) COMBINE(3) COMBINE(4) COMBINE(5) COMBINE(6) COMBINE(7) COMBINE(8)
+    default:
+      ZK_LAUNCH(ctx, "coset_combine", coset_combine_generic_kernel, grid, block, 0, (const Fr*)d_h, d_pieces, (uint32_t)n, d->nc, npieces,
+                (const Fr*)d->d_vinv261);
+  }
+#undef COMBINE
   return AMDZK_OK;
 }
 

@@ -35,6 +35,7 @@ struct amdzk_domain;
 int zk_msm_dev_xyzz(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const Fr* d_scalars, size_t ncols, size_t len, size_t col_stride,
                     G1X** d_out);
 int zk_msm_finish(amdzk_ctx* ctx, const G1X* d_res, size_t ncols, uint64_t* out_jac);
+int zk_lagrange_to_coeff(amdzk_ctx* ctx, const amdzk_domain* d, const Fr* d_in, size_t in_stride, Fr* d_out, size_t out_stride, size_t ncols);
 extern "C" {
 int amdzk_domain_new(amdzk_ctx* ctx, uint32_t j, uint32_t k, amdzk_domain** out);
 void amdzk_domain_free(amdzk_ctx* ctx, amdzk_domain* d);
@@ -147,15 +148,19 @@ struct amdzk_pk {
   Fr *l0_c = nullptr, *llast_c = nullptr, *lactive_c = nullptr, *x_coset = nullptr, *omega_pow = nullptr;
   // device: per-proof workspace. poly arena order: adv | inst | la | ls | zp | zl
   size_t NP = 0;
-  Fr *P = nullptr, *PC = nullptr;   // [NP][n], [NP][ext]
+  // P: the committed columns' Lagrange values [NP][n] (what commit_lagrange and the Lagrange-domain programs read);
+  // PQ: their coefficients [NP][n] (evaluations, multiopen); PC: their values on the quotient domain [NP][ext].
+  // Out of place, so that a phase's transforms run on a lane while its commitments and the next phase's programs
+  // still read the Lagrange values.
+  Fr *P = nullptr, *PQ = nullptr, *PC = nullptr;
   Fr *ci = nullptr, *ct = nullptr;  // [L][n] compressed lookup input / table
   Fr *rnd = nullptr, *hq = nullptr, *hpieces = nullptr, *hpoly = nullptr, *frac = nullptr, *scratch = nullptr, *scan_tmp = nullptr;
-  Fr *sets_L = nullptr, *sets_N = nullptr, *hx = nullptr;  // SHPLONK buffers
-  // AMDZK_MERGE_COMMITS=1 (read at keygen): permutation products, lookup products and the random polynomial are
-  // committed by ONE multi-scalar multiplication instead of three. A proof alone on the GPU is 1.2 ms shorter (the
-  // bucket folds of a batch are latency-bound launches); with a dozen proofs in flight the three smaller batches
-  // interleave better and prove 1.6 % more per second (profiles/r02m_ab_merged_commitments.txt) — hence off by default.
-  bool merge_commits = false;
+  Fr *frac2 = nullptr, *scratch2 = nullptr, *scan_tmp2 = nullptr;  // the lookup products' own scratch: they run beside the permutation products
+  Fr *sets_L = nullptr, *sets_N = nullptr, *sets_Q = nullptr, *hx = nullptr;  // SHPLONK buffers
+  // Lanes (common.hpp): 0 = the caller's ctx, 1 and 2 = its auxiliary streams. AMDZK_KEYGEN_SERIAL / AMDZK_SERIAL=1
+  // keeps everything on the caller's stream (one proof's kernels strictly one after another, as in rounds 1-2).
+  bool use_lanes = true;
+  uint32_t max_sets = 16, max_set_points = 0;
   // What the multiopen argument derives from the key alone, built by the first proof (the polynomials live at fixed
   // addresses in this key's workspace): the evaluation list, the query list and SHPLONK's rotation sets in terms of
   // rotations. Only the ORDER of a set's points (upstream keeps them in a BTreeSet of field elements) depends on x.
@@ -177,8 +182,12 @@ struct amdzk_pk {
   Fr *lk_ts = nullptr, *lk_left = nullptr;  // lookup permutation: sorted tables, leftovers [L][n]
   uint32_t* lk_flags = nullptr;              // [4][L][n+8]
   int* d_err = nullptr;
-  Fr* small = nullptr;  // misc small device buffer (blinding uploads, points, evals, coefs)
-  void* ptrs = nullptr;  // device pointer-table scratch
+  // misc small device buffers (blinding uploads, points, evals, coefs) and pointer-table scratch, one slice per lane:
+  // a slice is reused in stream order by the lane that owns it
+  Fr* small_l[3] = {nullptr, nullptr, nullptr};
+  void* ptrs_l[3] = {nullptr, nullptr, nullptr};
+  Fr* small = nullptr;   // = small_l[0]
+  void* ptrs = nullptr;  // = ptrs_l[0]
   size_t small_cap = 0, ptrs_cap = 0;
   // programs
   Program prog_compress, prog_pfrac, prog_lfrac, prog_h;
@@ -204,7 +213,11 @@ struct amdzk_pk {
   Fr* ls() { return P + (size_t)(A + I + L) * n; }
   Fr* zp() { return P + (size_t)(A + I + 2 * L) * n; }
   Fr* zl() { return P + (size_t)(A + I + 2 * L + nsets) * n; }
-  Fr* rnd_lagrange() { return P + NP * n; }  // column NP: not one of the NP polynomials that go to the cosets
+  Fr* q_adv() { return PQ; }
+  Fr* q_la() { return PQ + (size_t)(A + I) * n; }
+  Fr* q_ls() { return PQ + (size_t)(A + I + L) * n; }
+  Fr* q_zp() { return PQ + (size_t)(A + I + 2 * L) * n; }
+  Fr* q_zl() { return PQ + (size_t)(A + I + 2 * L + nsets) * n; }
   // slots, Lagrange table
   uint32_t sl_fixed(uint32_t c) { return c; }
   uint32_t sl_adv(uint32_t c) { return F + c; }
@@ -251,8 +264,8 @@ int h2d_staged(amdzk_ctx* ctx, amdzk_pk* pk, void* d, const void* h, size_t byte
   if (!bytes) return AMDZK_OK;
   if (!pk->pin || bytes > pk->pin_cap) return h2d(ctx, d, h, bytes);
   size_t off = (pk->pin_off + 63) & ~(size_t)63;
-  if (off + bytes > pk->pin_cap) {
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (off + bytes > pk->pin_cap) {  // wrap: every stream that may still be reading the staging area must be done with it
+    ZK_TRY(zk_sync_all(ctx));
     off = 0;
   }
   memcpy(pk->pin + off, h, bytes);
@@ -297,14 +310,29 @@ int zk_permute_expression_pairs(amdzk_ctx* ctx, Fr* A, const Fr* T, Fr* Ts, Fr* 
   return AMDZK_OK;
 }
 
-// MSM of ncols resident columns -> affine points on the host
-int commit_cols(amdzk_ctx* ctx, amdzk_pk* pk, int basis, const Fr* d_cols, size_t ncols, std::vector<G1Affine>& out) {
+// MSM of ncols resident columns -> affine points on the host, in two halves: commit_launch enqueues the kernels on
+// `ctx`'s stream (a lane or the caller's ctx) and returns; commit_finish copies the result down and waits for that
+// stream only. Between the two the host enqueues work on other lanes. One commitment batch per lane at a time (the
+// result sits in the lane's MSM workspace until it is finished).
+struct PendingCommit {
+  amdzk_ctx* ctx = nullptr;
+  G1X* d_res = nullptr;
+  size_t ncols = 0;
+};
+int commit_launch(amdzk_ctx* ctx, amdzk_pk* pk, int basis, const Fr* d_cols, size_t ncols, PendingCommit& pc) {
+  pc.ctx = ctx;
+  pc.ncols = ncols;
+  pc.d_res = nullptr;
+  if (ncols == 0) return AMDZK_OK;
+  return zk_msm_dev_xyzz(ctx, pk->srs, basis, d_cols, ncols, pk->n, pk->n, &pc.d_res);
+}
+int commit_finish(PendingCommit& pc, std::vector<G1Affine>& out) {
+  amdzk_ctx* ctx = pc.ctx;
+  const size_t ncols = pc.ncols;
   out.resize(ncols);
   if (ncols == 0) return AMDZK_OK;
-  G1X* d_res = nullptr;
-  ZK_TRY(zk_msm_dev_xyzz(ctx, pk->srs, basis, d_cols, ncols, pk->n, pk->n, &d_res));
   std::vector<uint64_t> jac(12 * ncols);
-  ZK_TRY(zk_msm_finish(ctx, d_res, ncols, jac.data()));
+  ZK_TRY(zk_msm_finish(ctx, pc.d_res, ncols, jac.data()));
   for (size_t i = 0; i < ncols; i++) {
     const G1Jac* j = reinterpret_cast<const G1Jac*>(&jac[12 * i]);
     if (j->z.is_zero()) {
@@ -316,6 +344,11 @@ int commit_cols(amdzk_ctx* ctx, amdzk_pk* pk, int basis, const Fr* d_cols, size_
     }
   }
   return AMDZK_OK;
+}
+int commit_cols(amdzk_ctx* ctx, amdzk_pk* pk, int basis, const Fr* d_cols, size_t ncols, std::vector<G1Affine>& out) {
+  PendingCommit pc;
+  ZK_TRY(commit_launch(ctx, pk, basis, d_cols, ncols, pc));
+  return commit_finish(pc, out);
 }
 
 // Translate a host-format postfix expression into device ops. The postfix words are first rebuilt
@@ -755,11 +788,10 @@ void trace_pt(const char* label, const G1Affine& p) {
 }  // namespace
 
 // plonk::evaluation::Evaluator::evaluate_h + divide_by_vanishing_poly + extended_to_coeff + the split into pieces
-// (SURVEY.md §8(a) rows a6, a7, a10): from the committed polynomials in coefficient form (pk->P, arena order) and the
+// (SURVEY.md §8(a) rows a6, a7, a10): from the committed polynomials in coefficient form (pk->PQ, arena order) and the
 // challenges in pk->consts to the degree-1 pieces of h(X) in pk->hpieces. The numerator is evaluated on nc cosets of
 // the size-n subgroup (poly.hip, zk_quotient_plan), then divided by X^n - 1, interpolated per coset and recombined.
-static int quotient_pieces(amdzk_ctx* ctx, amdzk_pk* pk) {
-  ZK_TRY(zk_coeff_to_cosets_r261(ctx, pk->dom, pk->P, pk->n, pk->PC, pk->ext, pk->NP));
+static int quotient_from_cosets(amdzk_ctx* ctx, amdzk_pk* pk) {
   ZK_TRY(upload_consts261(ctx, pk));
   ZK_TRY(upload_ypow(ctx, pk));
   // the program writes h where its first group of terms is flushed: a constraint system without a single term has none
@@ -767,6 +799,10 @@ static int quotient_pieces(amdzk_ctx* ctx, amdzk_pk* pk) {
   ZK_TRY(run_program(ctx, pk, pk->prog_h, true, nullptr, pk->hq, "expr_evaluate_h"));
   ZK_TRY(zk_cosets_to_pieces(ctx, pk->dom, pk->hq, pk->hpieces, pk->qdeg));
   return AMDZK_OK;
+}
+static int quotient_pieces(amdzk_ctx* ctx, amdzk_pk* pk) {
+  ZK_TRY(zk_coeff_to_cosets_r261(ctx, pk->dom, pk->PQ, pk->n, pk->PC, pk->ext, pk->NP));
+  return quotient_from_cosets(ctx, pk);
 }
 
 extern "C" {
@@ -789,10 +825,21 @@ int amdzk_pk_check_affinity(amdzk_ctx* ctx, const amdzk_pk* pk) {
   return AMDZK_OK;
 }
 
+// keygen with the environment's defaults for the key's modes (AMDZK_FULL_COSETS, AMDZK_SERIAL); amdzk_keygen_ex takes
+// them as explicit flags, so that two keys of one process can differ.
 int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, const uint64_t* fixed_values, const uint32_t* perm_mapping,
                  const uint64_t transcript_repr[4], amdzk_pk** out) {
+  uint32_t flags = 0;
+  if (const char* e = getenv("AMDZK_FULL_COSETS")) flags |= atoi(e) != 0 || !*e ? AMDZK_KEYGEN_FULL_COSETS : 0u;
+  if (const char* e = getenv("AMDZK_SERIAL")) flags |= atoi(e) != 0 ? AMDZK_KEYGEN_SERIAL : 0u;
+  return amdzk_keygen_ex(ctx, srs, c, fixed_values, perm_mapping, transcript_repr, flags, out);
+}
+
+int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, const uint64_t* fixed_values, const uint32_t* perm_mapping,
+                    const uint64_t transcript_repr[4], uint32_t flags, amdzk_pk** out) {
   ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
+  if (flags & ~(uint32_t)(AMDZK_KEYGEN_FULL_COSETS | AMDZK_KEYGEN_SERIAL)) ZK_FAIL(ctx, AMDZK_E_INVALID, "keygen: unknown flags %#x", flags);
   if (!srs || !c || !out || !transcript_repr) ZK_FAIL(ctx, AMDZK_E_INVALID, "keygen: null argument");
   if (c->cs_degree < 3) ZK_FAIL(ctx, AMDZK_E_INVALID, "keygen: cs_degree %u < 3", c->cs_degree);
   amdzk_pk* pk = new amdzk_pk();
@@ -826,7 +873,8 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
   pk->ek = amdzk_domain_extended_k(pk->dom);
   // h(X) has qdeg = degree - 1 pieces: that many cosets pin it down (AMDZK_FULL_COSETS=1: all 2^(ek-k), upstream's own
   // computation — identical output for satisfying witnesses, and the way to reproduce upstream's bytes for others)
-  pk->nc = getenv("AMDZK_FULL_COSETS") ? (1u << (pk->ek - pk->k)) : pk->qdeg;
+  pk->nc = (flags & AMDZK_KEYGEN_FULL_COSETS) ? (1u << (pk->ek - pk->k)) : pk->qdeg;
+  pk->use_lanes = !(flags & AMDZK_KEYGEN_SERIAL);
   KG_TRY(zk_quotient_plan(ctx, pk->dom, pk->nc));
   pk->ext = (size_t)pk->nc * pk->n;
   amdzk_domain_constant(pk->dom, 0, (uint64_t*)pk->omega.l);
@@ -875,8 +923,8 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
   KG_TRY(dalloc(ctx, pk, &pk->x_coset, ext));
   KG_TRY(dalloc(ctx, pk, &pk->omega_pow, n));
   pk->NP = (size_t)A + I + 2 * L + ns + L;
-  if (const char* e = getenv("AMDZK_MERGE_COMMITS")) pk->merge_commits = atoi(e) != 0;
-  KG_TRY(dalloc(ctx, pk, &pk->P, (pk->NP + 1) * n));  // + the random polynomial's Lagrange values, committed with the product columns
+  KG_TRY(dalloc(ctx, pk, &pk->P, pk->NP * n));
+  KG_TRY(dalloc(ctx, pk, &pk->PQ, pk->NP * n));
   KG_TRY(dalloc(ctx, pk, &pk->PC, pk->NP * ext));
   KG_TRY(dalloc(ctx, pk, &pk->ci, (size_t)L * n));
   KG_TRY(dalloc(ctx, pk, &pk->ct, (size_t)L * n));
@@ -892,23 +940,28 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
   KG_TRY(dalloc(ctx, pk, &pk->frac, nfrac * n));
   KG_TRY(dalloc(ctx, pk, &pk->scratch, std::max(nfrac * n, ext)));
   KG_TRY(dalloc(ctx, pk, &pk->scan_tmp, zk_scan_totals_elems(n, nfrac) + 2 * nfrac + 8));
-  const size_t max_rsets = 16;
+  KG_TRY(dalloc(ctx, pk, &pk->frac2, std::max<size_t>(L, 1) * n));
+  KG_TRY(dalloc(ctx, pk, &pk->scratch2, std::max<size_t>(L, 1) * n));
+  KG_TRY(dalloc(ctx, pk, &pk->scan_tmp2, zk_scan_totals_elems(n, std::max<size_t>(L, 1)) + 2 * std::max<size_t>(L, 1) + 8));
+  const size_t max_rsets = pk->max_sets;
   KG_TRY(dalloc(ctx, pk, &pk->sets_L, max_rsets * n));
   KG_TRY(dalloc(ctx, pk, &pk->sets_N, max_rsets * n));
   KG_TRY(dalloc(ctx, pk, &pk->hx, n));
   pk->small_cap = std::max<size_t>((size_t)pk->NP * (pk->bf + 2) + 4096, 8192);
-  KG_TRY(dalloc(ctx, pk, &pk->small, pk->small_cap));
+  for (int l = 0; l < 3; l++) KG_TRY(dalloc(ctx, pk, &pk->small_l[l], pk->small_cap));
+  pk->small = pk->small_l[0];
   pk->pin_cap = std::max<size_t>((size_t)8 << 20, 2 * n * 32);
   if (hipHostMalloc((void**)&pk->pin, pk->pin_cap, hipHostMallocDefault) != hipSuccess) {
     pk->pin = nullptr;
     pk->pin_cap = 0;
   }
   pk->ptrs_cap = 8192;
-  {
+  for (int l = 0; l < 3; l++) {
     void** pp = nullptr;
     KG_TRY(dalloc(ctx, pk, &pp, pk->ptrs_cap));
-    pk->ptrs = pp;
+    pk->ptrs_l[l] = pp;
   }
+  pk->ptrs = pk->ptrs_l[0];
 
   // ---- host-side tables: omega powers, coset points, l0 / l_last / l_blind (Lagrange)
   {
@@ -1087,7 +1140,7 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
     KG_TRY(h2d(ctx, pk->d_outs_pfrac, outs.data(), outs.size() * sizeof(Fr*)));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
-  // (3) lookup fractions: den = (a'+beta)(s'+gamma) -> frac[l]; num = (ci+beta)(ct+gamma) -> zl[l]
+  // (3) lookup fractions: den = (a'+beta)(s'+gamma) -> frac2[l]; num = (ci+beta)(ct+gamma) -> zl[l]
   {
     Program& pr = pk->prog_lfrac;
     for (uint32_t l = 0; l < L; l++) {
@@ -1113,7 +1166,7 @@ int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c, c
       pr.pop();
     }
     std::vector<Fr*> outs(2 * L);
-    for (uint32_t l = 0; l < L; l++) outs[2 * l] = pk->frac + (size_t)l * n, outs[2 * l + 1] = pk->zl() + (size_t)l * n;
+    for (uint32_t l = 0; l < L; l++) outs[2 * l] = pk->frac2 + (size_t)l * n, outs[2 * l + 1] = pk->zl() + (size_t)l * n;  // frac2: beside the permutation products
     KG_TRY(dalloc(ctx, pk, &pk->d_outs_lfrac, outs.size()));
     KG_TRY(h2d(ctx, pk->d_outs_lfrac, outs.data(), outs.size() * sizeof(Fr*)));
     ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1370,11 +1423,25 @@ int amdzk_create_proof_ex(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* i
   return create_proof_impl(ctx, pk, instances, instance_lens, d_advice, advice_stride, rs, transcript_kind, proof_out, proof_cap, proof_len);
 }
 
+static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances, const size_t* instance_lens, const void* d_advice,
+                             size_t advice_stride, RandomSource& rng, int transcript_kind, uint8_t* proof_out, size_t proof_cap,
+                             size_t* proof_len);
 static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances, const size_t* instance_lens, const void* d_advice,
                              size_t advice_stride, RandomSource& rng, int transcript_kind, uint8_t* proof_out, size_t proof_cap,
                              size_t* proof_len) {
   ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
+  const int r = create_proof_body(ctx, pk, instances, instance_lens, d_advice, advice_stride, rng, transcript_kind, proof_out, proof_cap, proof_len);
+  if (r != AMDZK_OK) {  // a failed proof may have left work on the lanes: the key's workspace must be quiet before it is used again
+    const std::string keep = ctx->err;
+    (void)zk_sync_all(ctx);
+    ctx->err = keep;
+  }
+  return r;
+}
+static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances, const size_t* instance_lens, const void* d_advice,
+                             size_t advice_stride, RandomSource& rng, int transcript_kind, uint8_t* proof_out, size_t proof_cap,
+                             size_t* proof_len) {
   if (!pk || !proof_len || (pk->A && !d_advice)) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: null argument");
   const size_t n = pk->n;
   const uint32_t F = pk->F, A = pk->A, I = pk->I, S = pk->S, L = pk->L, ns = pk->nsets, bf = pk->bf;
@@ -1397,10 +1464,35 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     fprintf(stderr, "[amdzk-time] %-28s %8.3f ms\n", label, t - tlast);
     tlast = t;
   };
-  auto upload_small = [&](const std::vector<Fr>& v, size_t off_elems) -> int {
+  // Lanes: M = the caller's ctx (everything the transcript waits for), B and C = its auxiliary streams (common.hpp).
+  // M carries the chain commitment -> challenge -> next phase; B takes each phase's columns to coefficient form and to
+  // the quotient domain as soon as they are blinded (out of place: the commitments and the next phase's programs keep
+  // reading the Lagrange values); C computes the lookup products beside the permutation products and commits the random
+  // polynomial at the very start. Only the ORDER OF TRANSCRIPT WRITES is upstream's;
+  // the arithmetic between two challenges is unordered there too. With AMDZK_KEYGEN_SERIAL, or while per-kernel
+  // profiling is on, B = C = M and everything below degenerates to one stream.
+  amdzk_ctx *M = ctx, *B = ctx, *C = ctx;
+  if (pk->use_lanes) {
+    ZK_TRY(zk_lane(ctx, 0, &B));
+    ZK_TRY(zk_lane(ctx, 1, &C));
+  }
+  const bool serial = B == M;
+  auto lane_id = [&](amdzk_ctx* l) { return l == M ? 0 : l == B ? 1 : 2; };
+// a failure on a lane is reported through the caller's ctx
+#define LN_TRY(lane, expr)                                  \
+  do {                                                      \
+    int _lr = (expr);                                       \
+    if (_lr != AMDZK_OK) {                                  \
+      if ((lane) != ctx) ctx->err = (lane)->err;            \
+      return _lr;                                           \
+    }                                                       \
+  } while (0)
+  auto upload_small_on = [&](amdzk_ctx* l, const std::vector<Fr>& v, size_t off_elems) -> int {
     if (off_elems + v.size() > pk->small_cap) ZK_FAIL(ctx, AMDZK_E_NOMEM, "create_proof: small buffer overflow");
-    return h2d_staged(ctx, pk, pk->small + off_elems, v.data(), v.size() * 32);
+    LN_TRY(l, h2d_staged(l, pk, pk->small_l[lane_id(l)] + off_elems, v.data(), v.size() * 32));
+    return AMDZK_OK;
   };
+  auto upload_small = [&](const std::vector<Fr>& v, size_t off_elems) -> int { return upload_small_on(M, v, off_elems); };
   auto write_points = [&](const std::vector<G1Affine>& pts, const char* label) -> int {
     for (auto& p : pts) {
       trace_pt(label, p);
@@ -1408,10 +1500,36 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     }
     return AMDZK_OK;
   };
-  // blinding tails: draw cnt scalars per column (column-major draw order), scatter into rows [row0, row0+cnt)
-  auto blind_rows = [&](Fr* d_cols, uint32_t ncols, size_t row0, uint32_t cnt, const std::vector<Fr>& vals) -> int {
-    ZK_TRY(upload_small(vals, 0));  // staged through pinned memory: `vals` may die right after
-    ZK_TRY(zk_scatter_rows(ctx, d_cols, n, row0, pk->small, cnt, ncols));
+  // blinding tails: cnt scalars per column (column-major draw order) scattered into rows [row0, row0+cnt), on lane l
+  auto blind_rows = [&](amdzk_ctx* l, Fr* d_cols, uint32_t ncols, size_t row0, uint32_t cnt, const std::vector<Fr>& vals) -> int {
+    ZK_TRY(upload_small_on(l, vals, 0));  // staged through pinned memory: `vals` may die right after
+    LN_TRY(l, zk_scatter_rows(l, d_cols, n, row0, pk->small_l[lane_id(l)], cnt, ncols));
+    return AMDZK_OK;
+  };
+  // A commitment batch begun on a lane and collected when the transcript needs it. On one stream (serial) it is
+  // collected at once: a context holds one batch's result at a time.
+  struct Commit {
+    PendingCommit pc;
+    std::vector<G1Affine> pts;
+    bool begun = false, done = false;
+  };
+  auto commit_end = [&](Commit& c) -> int {
+    if (c.begun && !c.done) LN_TRY(c.pc.ctx, commit_finish(c.pc, c.pts));
+    c.done = true;
+    return AMDZK_OK;
+  };
+  auto commit_begin = [&](amdzk_ctx* l, int basis, const Fr* d_cols, size_t ncols, Commit& c) -> int {
+    LN_TRY(l, commit_launch(l, pk, basis, d_cols, ncols, c.pc));
+    c.begun = true;
+    if (serial) ZK_TRY(commit_end(c));
+    return AMDZK_OK;
+  };
+  // columns [first, first + count) of the arena, blinded on lane `after`: coefficients (PQ) and quotient-domain values (PC) on B
+  auto transforms_on_B = [&](amdzk_ctx* after, size_t first, size_t count) -> int {
+    if (!count) return AMDZK_OK;
+    ZK_TRY(zk_stream_after(B, after));
+    LN_TRY(B, zk_lagrange_to_coeff(B, pk->dom, pk->P + first * n, n, pk->PQ + first * n, n, count));
+    LN_TRY(B, zk_coeff_to_cosets_r261(B, pk->dom, pk->PQ + first * n, n, pk->PC + first * pk->ext, pk->ext, count));
     return AMDZK_OK;
   };
 
@@ -1434,17 +1552,38 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
       if (!pk->pin || len * 32 > pk->pin_cap) ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
   }
+  // The random polynomial of the vanishing argument (step 5 below) depends on nothing but the RNG: its n draws follow
+  // all blinding draws, whose number is fixed by the key, so they are taken from that position of the stream now —
+  // generated and committed on lane C while M commits the advice columns.
+  const size_t draws_before_random = (size_t)A * (bf + 1) + A + (size_t)L * (2 * (bf + 1) + 2) + (size_t)ns * (bf + 1) + (size_t)L * (bf + 1);
+  Commit cm_rnd, cm_zp, cm_zl;
+  {
+    ZK_TRY(zk_stream_after(C, M));  // the previous proof on this key may still be reading rnd on M's stream
+    if (rng.rng) {
+      // ChaCha20Rng: every draw is one key-stream block, so draw j of the stream is block j: one kernel
+      if (!rng.rng->at_block_boundary()) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: RNG stream not on a block boundary");
+      LN_TRY(C, zk_chacha20_fr_random(C, pk->rnd, n, rng.rng->key(), rng.rng->block_counter() + draws_before_random, zkhost::fr_r3()));
+    } else {  // the caller's own RngCore: its pre-drawn scalars
+      if (draws_before_random + n > rng.count) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: ran out of caller-supplied random scalars");
+      LN_TRY(C, h2d(C, pk->rnd, rng.scalars + 4 * draws_before_random, n * 32));  // the caller's buffer outlives the call
+    }
+    ZK_TRY(commit_begin(C, AMDZK_BASIS_G, pk->rnd, 1, cm_rnd));
+  }
   // 1. advice: copy in, blind the unusable rows of every column, draw the (unused) blinds, commit
   if (A) {
     ZK_HIP(ctx, hipMemcpy2DAsync(pk->adv(), n * 32, d_advice, advice_stride * 32, n * 32, A, hipMemcpyDeviceToDevice, ctx->stream));
     std::vector<Fr> tail((size_t)A * (bf + 1));
     for (auto& v : tail) v = rng.fr();
     for (uint32_t c = 0; c < A; c++) (void)rng.fr();
-    ZK_TRY(blind_rows(pk->adv(), A, usable, bf + 1, tail));
+    ZK_TRY(blind_rows(M, pk->adv(), A, usable, bf + 1, tail));
+  }
+  ZK_TRY(transforms_on_B(M, 0, (size_t)A + I));
+  if (A) {
     std::vector<G1Affine> cm;
     ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G_LAGRANGE, pk->adv(), A, cm));
     ZK_TRY(write_points(cm, "advice"));
   }
+  ZK_TRY(commit_end(cm_rnd));  // long done; lane C's MSM workspace is free for the lookup products' commitment
   tick("advice");
   Fr theta = T.squeeze_challenge();
   trace_fr("theta", theta);
@@ -1465,8 +1604,10 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
       (void)rng.fr();
       (void)rng.fr();
     }
-    ZK_TRY(blind_rows(pk->la(), L, usable, bf + 1, ta));
-    ZK_TRY(blind_rows(pk->ls(), L, usable, bf + 1, ts));
+    ZK_TRY(blind_rows(M, pk->la(), L, usable, bf + 1, ta));
+    ZK_TRY(upload_small(ts, ta.size()));
+    ZK_TRY(zk_scatter_rows(ctx, pk->ls(), n, usable, pk->small + ta.size(), bf + 1, L));
+    ZK_TRY(transforms_on_B(M, (size_t)A + I, 2 * (size_t)L));
     std::vector<G1Affine> cm;
     ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G_LAGRANGE, pk->la(), 2 * L, cm));
     for (uint32_t l = 0; l < L; l++) {
@@ -1489,92 +1630,60 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     }
     ZK_TRY(h2d_staged(ctx, pk, pk->d_consts + pk->c_beta, &pk->consts[pk->c_beta], (size_t)(pk->consts.size() - pk->c_beta) * 32));
   }
-  // 3. permutation grand products
   tick("  perm: challenges+consts");
+  // 3. + 4. permutation grand products on M, lookup grand products on C (they depend on beta and gamma only, not on
+  // each other). RNG order: the permutation sets' tails and blinds, then the lookups'.
+  std::vector<Fr> tail_p((size_t)ns * bf), tail_l((size_t)L * bf);
+  for (uint32_t s = 0; s < ns; s++) {
+    for (uint32_t i = 0; i < bf; i++) tail_p[(size_t)s * bf + i] = rng.fr();
+    (void)rng.fr();
+  }
+  for (uint32_t l = 0; l < L; l++) {
+    for (uint32_t i = 0; i < bf; i++) tail_l[(size_t)l * bf + i] = rng.fr();
+    (void)rng.fr();
+  }
+  // 5. vanishing: the random polynomial's n draws and its blind (generated above from this position of the stream)
+  if (rng.rng) rng.rng->skip_blocks(n);
+  else rng.used += n;
+  (void)rng.fr();
+  if (L) {
+    ZK_TRY(zk_stream_after(C, M));  // beta, gamma and the permuted columns are in place
+    LN_TRY(C, run_program(C, pk, pk->prog_lfrac, false, pk->d_outs_lfrac, nullptr, "expr_lookup_fractions"));
+    LN_TRY(C, zk_batch_invert(C, pk->frac2, pk->scratch2, (size_t)L * n));
+    LN_TRY(C, zk_mul_elem(C, pk->zl(), pk->frac2, (size_t)L * n));
+    LN_TRY(C, zk_running_product(C, pk->zl(), L, n, n, false, 0, pk->scan_tmp2));
+    ZK_TRY(blind_rows(C, pk->zl(), L, n - bf, bf, tail_l));
+  }
   if (ns) {
     ZK_TRY(run_program(ctx, pk, pk->prog_pfrac, false, pk->d_outs_pfrac, nullptr, "expr_perm_fractions"));
     tick("  perm: fractions program");
     ZK_TRY(zk_batch_invert(ctx, pk->frac, pk->scratch, (size_t)ns * n));
     tick("  perm: batch invert");
     ZK_TRY(zk_mul_elem(ctx, pk->zp(), pk->frac, (size_t)ns * n));
-    tick("  perm: fractions+invert");
     ZK_TRY(zk_running_product(ctx, pk->zp(), ns, n, n, true, usable, pk->scan_tmp));
     tick("  perm: running product");
-    std::vector<Fr> tail((size_t)ns * bf);
-    for (uint32_t s = 0; s < ns; s++) {
-      for (uint32_t i = 0; i < bf; i++) tail[(size_t)s * bf + i] = rng.fr();
-      (void)rng.fr();
-    }
-    ZK_TRY(blind_rows(pk->zp(), ns, n - bf, bf, tail));
-    tick("  perm: blind");
-    if (!pk->merge_commits) {
-      std::vector<G1Affine> cm;
-      ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G_LAGRANGE, pk->zp(), ns, cm));
-      ZK_TRY(write_points(cm, "perm_z"));
-    }
+    ZK_TRY(blind_rows(M, pk->zp(), ns, n - bf, bf, tail_p));
+    ZK_TRY(transforms_on_B(M, (size_t)A + I + 2 * L, ns));
+    ZK_TRY(commit_begin(M, AMDZK_BASIS_G_LAGRANGE, pk->zp(), ns, cm_zp));
   }
-  tick("perm_products");
-  // 4. lookup grand products
   if (L) {
-    ZK_TRY(run_program(ctx, pk, pk->prog_lfrac, false, pk->d_outs_lfrac, nullptr, "expr_lookup_fractions"));
-    ZK_TRY(zk_batch_invert(ctx, pk->frac, pk->scratch, (size_t)L * n));
-    ZK_TRY(zk_mul_elem(ctx, pk->zl(), pk->frac, (size_t)L * n));
-    ZK_TRY(zk_running_product(ctx, pk->zl(), L, n, n, false, 0, pk->scan_tmp));
-    std::vector<Fr> tail((size_t)L * bf);
-    for (uint32_t l = 0; l < L; l++) {
-      for (uint32_t i = 0; i < bf; i++) tail[(size_t)l * bf + i] = rng.fr();
-      (void)rng.fr();
-    }
-    ZK_TRY(blind_rows(pk->zl(), L, n - bf, bf, tail));
-    if (!pk->merge_commits) {
-      std::vector<G1Affine> cm;
-      ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G_LAGRANGE, pk->zl(), L, cm));
-      ZK_TRY(write_points(cm, "lookup_z"));
-    }
+    ZK_TRY(transforms_on_B(C, (size_t)A + I + 2 * L + ns, L));
+    ZK_TRY(commit_begin(C, AMDZK_BASIS_G_LAGRANGE, pk->zl(), L, cm_zl));
   }
+  ZK_TRY(commit_end(cm_zp));
+  ZK_TRY(write_points(cm_zp.pts, "perm_z"));
+  tick("perm_products");
+  ZK_TRY(commit_end(cm_zl));
+  ZK_TRY(write_points(cm_zl.pts, "lookup_z"));
   tick("lookup_products");
-  // 5. vanishing: the random polynomial (coefficient form). Its draws follow the blinding rows above, as upstream's do.
-  {
-    if (rng.rng && rng.rng->at_block_boundary()) {
-      // ChaCha20Rng: draw j of the stream is key-stream block j, so the n coefficients come from one kernel
-      ZK_TRY(zk_chacha20_fr_random(ctx, pk->rnd, n, rng.rng->key(), rng.rng->block_counter(), zkhost::fr_r3()));
-      rng.rng->skip_blocks(n);
-    } else {  // the caller's own RngCore: its pre-drawn scalars
-      std::vector<Fr> rp(n);
-      for (auto& v : rp) v = rng.fr();
-      ZK_TRY(h2d_staged(ctx, pk, pk->rnd, rp.data(), n * 32));
-      if (!pk->pin || n * 32 > pk->pin_cap) ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `rp` is a temporary
-    }
-    (void)rng.fr();
-    tick("  random: rng");
-  }
-  if (pk->merge_commits) {
-    // The lookup products depend on beta and gamma only, not on the permutation products' commitments, and the random
-    // polynomial on neither: one multi-scalar multiplication commits all three. The product columns are adjacent in the
-    // key's workspace; the random polynomial joins them as its Lagrange values (one more transform of size n):
-    // committing those with g_lagrange is committing its coefficients with g — the same group element for any
-    // well-formed parameters (g_lagrange = the Lagrange basis of g). Written in upstream's order.
-    ZK_TRY(d2d(ctx, pk->rnd_lagrange(), pk->rnd, n * 32));
-    ZK_TRY(amdzk_coeff_to_lagrange_dev(ctx, pk->dom, pk->rnd_lagrange(), 1, n));
-    std::vector<G1Affine> cm;
-    ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G_LAGRANGE, pk->zp(), ns + L + 1, cm));
-    std::vector<G1Affine> pz(cm.begin(), cm.begin() + ns), lz(cm.begin() + ns, cm.begin() + ns + L), rz(cm.begin() + ns + L, cm.end());
-    ZK_TRY(write_points(pz, "perm_z"));
-    ZK_TRY(write_points(lz, "lookup_z"));
-    ZK_TRY(write_points(rz, "random_poly"));
-  } else {
-    std::vector<G1Affine> cm;
-    ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G, pk->rnd, 1, cm));
-    ZK_TRY(write_points(cm, "random_poly"));
-  }
-  tick("random_poly");
+  ZK_TRY(write_points(cm_rnd.pts, "random_poly"));
   Fr y = T.squeeze_challenge();
   trace_fr("y", y);
   pk->consts[pk->c_y] = y;
   ZK_TRY(h2d_staged(ctx, pk, pk->d_consts + pk->c_y, &pk->consts[pk->c_y], 32));
-  // 6. every committed column: Lagrange -> coefficients -> extended coset; then h(X)
-  ZK_TRY(amdzk_lagrange_to_coeff_dev(ctx, pk->dom, pk->P, pk->NP, n));
-  ZK_TRY(quotient_pieces(ctx, pk));  // theta, beta, gamma, delta powers, y are all known by now
+  // 6. h(X): every committed column is on the quotient domain once lane B has drained
+  ZK_TRY(zk_stream_after(M, B));
+  ZK_TRY(quotient_from_cosets(ctx, pk));  // theta, beta, gamma, delta powers, y are all known by now
   {
     for (uint32_t i = 0; i < pk->qdeg; i++) (void)rng.fr();  // h_blinds
     std::vector<G1Affine> cm;
@@ -1602,7 +1711,7 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
   // 7. evaluations. One list of (polynomial, rotation) in proof order, then the two extra
   //    evaluations SHPLONK needs (h_poly at x; random at x is already in the list).
   amdzk_pk::Multiopen& mo = pk->mo;
-  Fr* adv_poly = pk->adv();
+  Fr* adv_poly = pk->q_adv();
   if (!mo.built) {
     auto rot_id = [&](int rot) -> uint32_t {
       for (size_t i = 0; i < mo.rots.size(); i++)
@@ -1619,16 +1728,16 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     addq(pk->rnd, 0);
     for (uint32_t i = 0; i < S; i++) addq(pk->sigma_poly + (size_t)i * n, 0);
     for (uint32_t s = 0; s < ns; s++) {
-      addq(pk->zp() + (size_t)s * n, 0);
-      addq(pk->zp() + (size_t)s * n, 1);
-      if (s + 1 < ns) addq(pk->zp() + (size_t)s * n, -(int)(bf + 1));
+      addq(pk->q_zp() + (size_t)s * n, 0);
+      addq(pk->q_zp() + (size_t)s * n, 1);
+      if (s + 1 < ns) addq(pk->q_zp() + (size_t)s * n, -(int)(bf + 1));
     }
     for (uint32_t l = 0; l < L; l++) {
-      addq(pk->zl() + (size_t)l * n, 0);
-      addq(pk->zl() + (size_t)l * n, 1);
-      addq(pk->la() + (size_t)l * n, 0);
-      addq(pk->la() + (size_t)l * n, -1);
-      addq(pk->ls() + (size_t)l * n, 0);
+      addq(pk->q_zl() + (size_t)l * n, 0);
+      addq(pk->q_zl() + (size_t)l * n, 1);
+      addq(pk->q_la() + (size_t)l * n, 0);
+      addq(pk->q_la() + (size_t)l * n, -1);
+      addq(pk->q_ls() + (size_t)l * n, 0);
     }
     mo.n_written = mo.ev.size();
     addq(pk->hpoly, 0);
@@ -1648,16 +1757,16 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     };
     for (auto& q : pk->advice_queries) addpq(adv_poly + (size_t)q.first * n, q.second);
     for (uint32_t s = 0; s < ns; s++) {
-      addpq(pk->zp() + (size_t)s * n, 0);
-      addpq(pk->zp() + (size_t)s * n, 1);
+      addpq(pk->q_zp() + (size_t)s * n, 0);
+      addpq(pk->q_zp() + (size_t)s * n, 1);
     }
-    for (int s = (int)ns - 2; s >= 0; s--) addpq(pk->zp() + (size_t)s * n, -(int)(bf + 1));
+    for (int s = (int)ns - 2; s >= 0; s--) addpq(pk->q_zp() + (size_t)s * n, -(int)(bf + 1));
     for (uint32_t l = 0; l < L; l++) {
-      addpq(pk->zl() + (size_t)l * n, 0);
-      addpq(pk->la() + (size_t)l * n, 0);
-      addpq(pk->ls() + (size_t)l * n, 0);
-      addpq(pk->la() + (size_t)l * n, -1);
-      addpq(pk->zl() + (size_t)l * n, 1);
+      addpq(pk->q_zl() + (size_t)l * n, 0);
+      addpq(pk->q_la() + (size_t)l * n, 0);
+      addpq(pk->q_ls() + (size_t)l * n, 0);
+      addpq(pk->q_la() + (size_t)l * n, -1);
+      addpq(pk->q_zl() + (size_t)l * n, 1);
     }
     for (auto& q : pk->fixed_queries) addpq(pk->fixed_poly + (size_t)q.first * n, q.second);
     for (uint32_t i = 0; i < S; i++) addpq(pk->sigma_poly + (size_t)i * n, 0);
@@ -1698,6 +1807,13 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
       hit->polys.push_back(cr_poly[c]);
       hit->ev_idx.push_back(evs);
     }
+    size_t pairs = 0;
+    for (auto& st : mo.sets) pairs += st.rot_ids.size();
+    if (mo.sets.size() > pk->max_sets) {
+      mo = amdzk_pk::Multiopen();
+      ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "create_proof: more than %u rotation sets", pk->max_sets);
+    }
+    ZK_TRY(dalloc(ctx, pk, &pk->sets_Q, std::max<size_t>(pairs, 1) * n));
     mo.built = true;
   }
   // the points x * omega^rot, once per distinct rotation
@@ -1818,60 +1934,68 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
         lows[i].push_back(std::move(low));
       }
     }
-    // L_i = sum_j y^j P_ij ; N_i = (L_i - sum_j y^j R_ij) / prod (X - p)
+    // L_i = sum_j y^j P_ij ; N_i = (L_i - R_i) / prod_t (X - p_t), R_i = sum_j y^j R_ij. The division runs once, not once
+    // per point: 1 / prod_t (X - p_t) = sum_t c_t / (X - p_t) with c_t = 1 / prod_{s != t} (p_t - p_s) (the points of a
+    // set are distinct), and L_i - R_i vanishes at every p_t, so N_i = sum_t c_t Q_it with Q_it = (L_i - R_i) / (X - p_t)
+    // — all (set, point) quotients in ONE division launch, then h(X) = sum_i v^i N_i = sum_it (v^i c_it) Q_it in one
+    // linear combination. Exact arithmetic, same polynomial. The L_i of different sets are independent: one lane each.
     size_t maxm = 0;
+    for (size_t i = 0; i < nr; i++) maxm = std::max(maxm, set_pts[i].size());
+    std::vector<const Fr*> q_src;
+    std::vector<Fr*> q_dst;
+    std::vector<Fr> q_root, q_low, q_coef;
+    amdzk_ctx* lanes3[3] = {M, B, C};
+    Fr vpow = Fr::one();
     for (size_t i = 0; i < nr; i++) {
-      const size_t m = mo.sets[i].polys.size();
+      const size_t m = mo.sets[i].polys.size(), np = set_pts[i].size();
       if (m > pk->ptrs_cap || m > pk->small_cap / 2) ZK_FAIL(ctx, AMDZK_E_NOMEM, "create_proof: rotation set too large");
       std::vector<Fr> cf(m);
       Fr cur = Fr::one();
-      std::vector<Fr> lowsum(set_pts[i].size(), Fr::zero());
+      std::vector<Fr> lowsum(np, Fr::zero());
       for (size_t j = 0; j < m; j++) {
         cf[j] = cur;
         for (size_t t = 0; t < lows[i][j].size(); t++) lowsum[t] = add(lowsum[t], mul(cur, lows[i][j][t]));
         cur = mul(cur, ys);
       }
-      maxm = std::max(maxm, set_pts[i].size());
-      ZK_TRY(h2d_staged(ctx, pk, pk->ptrs, mo.sets[i].polys.data(), m * sizeof(Fr*)));
-      ZK_TRY(upload_small(cf, 0));
-      ZK_TRY(upload_small(lowsum, m));
+      amdzk_ctx* ln = lanes3[i % 3];
+      const int li = lane_id(ln);
+      if (ln != M && i < 3) ZK_TRY(zk_stream_after(ln, M));  // the evaluations above came off M; hpoly is in place
+      LN_TRY(ln, h2d_staged(ln, pk, pk->ptrs_l[li], mo.sets[i].polys.data(), m * sizeof(Fr*)));
+      ZK_TRY(upload_small_on(ln, cf, 0));
       Fr* Li = pk->sets_L + i * n;
-      Fr* Ni = pk->sets_N + i * n;
-      ZK_TRY(zk_lincomb(ctx, (const Fr* const*)pk->ptrs, pk->small, (uint32_t)m, Li, n, false));
-      ZK_TRY(d2d(ctx, Ni, Li, n * 32));
-      ZK_TRY(zk_sub_low(ctx, Ni, pk->small + m, (uint32_t)lowsum.size()));
-    }
-    for (size_t step = 0; step < maxm; step++) {  // one root per set per launch
-      std::vector<Fr*> pp;
-      std::vector<Fr> roots;
-      for (size_t i = 0; i < nr; i++)
-        if (step < set_pts[i].size()) {
-          pp.push_back(pk->sets_N + i * n);
-          roots.push_back(set_pts[i][step]);
-        }
-      ZK_TRY(h2d_staged(ctx, pk, pk->ptrs, pp.data(), pp.size() * sizeof(Fr*)));
-      ZK_TRY(upload_small(roots, 0));
-      ZK_TRY(zk_kate_div(ctx, (Fr* const*)pk->ptrs, pk->small, pp.size(), (uint32_t)n));
-    }
-    {
-      std::vector<const Fr*> pp(nr);
-      std::vector<Fr> cf(nr);
-      Fr cur = Fr::one();
-      for (size_t i = 0; i < nr; i++) {
-        pp[i] = pk->sets_N + i * n;
-        cf[i] = cur;
-        cur = mul(cur, v);
+      LN_TRY(ln, zk_lincomb(ln, (const Fr* const*)pk->ptrs_l[li], pk->small_l[li], (uint32_t)m, Li, n, false));
+      for (size_t t = 0; t < np; t++) {
+        Fr den = Fr::one();
+        for (size_t s2 = 0; s2 < np; s2++)
+          if (s2 != t) den = mul(den, sub(set_pts[i][t], set_pts[i][s2]));
+        q_src.push_back(Li);
+        q_dst.push_back(pk->sets_Q + q_dst.size() * n);
+        q_root.push_back(set_pts[i][t]);
+        q_coef.push_back(mul(vpow, inv(den)));
+        for (size_t d = 0; d < maxm; d++) q_low.push_back(d < np ? lowsum[d] : Fr::zero());
       }
-      ZK_TRY(h2d_staged(ctx, pk, pk->ptrs, pp.data(), nr * sizeof(Fr*)));
-      ZK_TRY(upload_small(cf, 0));
-      ZK_TRY(zk_lincomb(ctx, (const Fr* const*)pk->ptrs, pk->small, (uint32_t)nr, pk->hx, n, false));
+      vpow = mul(vpow, v);
+    }
+    ZK_TRY(zk_stream_after(M, B));
+    ZK_TRY(zk_stream_after(M, C));
+    {
+      const size_t nq = q_dst.size();
+      if (2 * nq > pk->ptrs_cap || nq * (maxm + 2) > pk->small_cap) ZK_FAIL(ctx, AMDZK_E_NOMEM, "create_proof: too many opening points");
+      void** pt = (void**)pk->ptrs;
+      ZK_TRY(h2d_staged(ctx, pk, pt, q_dst.data(), nq * sizeof(Fr*)));
+      ZK_TRY(h2d_staged(ctx, pk, pt + nq, q_src.data(), nq * sizeof(Fr*)));
+      ZK_TRY(upload_small(q_root, 0));
+      ZK_TRY(upload_small(q_low, nq));
+      ZK_TRY(upload_small(q_coef, nq + q_low.size()));
+      ZK_TRY(zk_kate_div_from(ctx, (Fr* const*)pt, (const Fr* const*)(pt + nq), pk->small, pk->small + nq, (uint32_t)maxm, nq, (uint32_t)n));
+      ZK_TRY(zk_lincomb(ctx, (const Fr* const*)pt, pk->small + nq + q_low.size(), (uint32_t)nq, pk->hx, n, false));
     }
     std::vector<G1Affine> cm;
     ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G, pk->hx, 1, cm));
     ZK_TRY(write_points(cm, "shplonk_h1"));
     Fr u = T.squeeze_challenge();
     trace_fr("u", u);
-    // l(X) = sum_i v^i z_i (L_i - r_i) - zt(u) h(X);  then / (X - u) / z_0
+    // l(X) = sum_i v^i z_i (L_i - r_i) - zt(u) h(X);  then / (X - u) / z_0 — the factor 1 / z_0 rides in on the coefficients
     Fr zt = Fr::one();
     for (uint32_t r : super) zt = mul(zt, sub(u, rot_pt[r]));
     std::vector<const Fr*> pp(nr + 1);
@@ -1895,19 +2019,18 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     }
     pp[nr] = pk->hx;
     cf[nr] = neg(zt);
-    Fr* lx = pk->sets_N;  // reuse
+    const Fr z0inv = inv(z0);
+    for (auto& c : cf) c = mul(c, z0inv);
+    cterm = mul(cterm, z0inv);
+    Fr* lx = pk->sets_Q;  // reuse
     ZK_TRY(h2d_staged(ctx, pk, pk->ptrs, pp.data(), (nr + 1) * sizeof(Fr*)));
     ZK_TRY(upload_small(cf, 0));
-    std::vector<Fr> ct1 = {cterm};
-    ZK_TRY(upload_small(ct1, nr + 1));
+    std::vector<Fr> tailv = {cterm, u};
+    ZK_TRY(upload_small(tailv, nr + 1));
     ZK_TRY(zk_lincomb(ctx, (const Fr* const*)pk->ptrs, pk->small, (uint32_t)(nr + 1), lx, n, false));
-    ZK_TRY(zk_sub_low(ctx, lx, pk->small + nr + 1, 1));
     std::vector<Fr*> one_p = {lx};
-    std::vector<Fr> one_r = {u};
-    ZK_TRY(h2d_staged(ctx, pk, pk->ptrs, one_p.data(), sizeof(Fr*)));
-    ZK_TRY(upload_small(one_r, 0));
-    ZK_TRY(zk_kate_div(ctx, (Fr* const*)pk->ptrs, pk->small, 1, (uint32_t)n));
-    ZK_TRY(zk_scale(ctx, lx, n, inv(z0)));
+    ZK_TRY(h2d_staged(ctx, pk, (void**)pk->ptrs + nr + 1, one_p.data(), sizeof(Fr*)));
+    ZK_TRY(zk_kate_div_from(ctx, (Fr* const*)((void**)pk->ptrs + nr + 1), nullptr, pk->small + nr + 2, pk->small + nr + 1, 1, 1, (uint32_t)n));
     ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G, lx, 1, cm));
     ZK_TRY(write_points(cm, "shplonk_h2"));
   }
@@ -1920,6 +2043,7 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
   }
   (void)F;
   return AMDZK_OK;
+#undef LN_TRY
 }
 
 // ---- function-by-function entry points of the PLONK layer: the same kernels create_proof runs,
@@ -1935,7 +2059,7 @@ int amdzk_quotient_eval_dev(amdzk_ctx* ctx, amdzk_pk* pk, const void* d_polys, s
   if (!ctx) return AMDZK_E_INVALID;
   if (!pk || !d_polys || !theta || !beta || !gamma || !y || !d_pieces_out) ZK_FAIL(ctx, AMDZK_E_INVALID, "quotient_eval: null argument");
   if (poly_stride < pk->n) ZK_FAIL(ctx, AMDZK_E_INVALID, "quotient_eval: stride < n");
-  ZK_HIP(ctx, hipMemcpy2DAsync(pk->P, pk->n * 32, d_polys, poly_stride * 32, pk->n * 32, pk->NP, hipMemcpyDeviceToDevice, ctx->stream));
+  ZK_HIP(ctx, hipMemcpy2DAsync(pk->PQ, pk->n * 32, d_polys, poly_stride * 32, pk->n * 32, pk->NP, hipMemcpyDeviceToDevice, ctx->stream));
   memcpy(pk->consts[pk->c_theta].l, theta, 32);
   memcpy(pk->consts[pk->c_beta].l, beta, 32);
   memcpy(pk->consts[pk->c_gamma].l, gamma, 32);
@@ -1963,7 +2087,7 @@ int amdzk_pk_inspect(amdzk_ctx* ctx, const amdzk_pk* pk, int what, uint64_t* out
   size_t cnt = 0;
   Fr ch[4];
   if (what == 0) {
-    src = pk->P;
+    src = pk->PQ;
     cnt = pk->NP * pk->n;
   } else if (what == 2) {
     src = pk->hpieces;

@@ -75,6 +75,7 @@ def lib():
         "amdzk_extended_to_coeff_dev": (i32, [vp, vp, vp, sz, sz]),
         "amdzk_divide_by_vanishing_dev": (i32, [vp, vp, vp, sz, sz]),
         "amdzk_keygen": (i32, [vp, vp, vp, vp, vp, vp, C.POINTER(vp)]),
+        "amdzk_keygen_ex": (i32, [vp, vp, vp, vp, vp, vp, u32, C.POINTER(vp)]),
         "amdzk_pk_free": (None, [vp, vp]),
         "amdzk_pk_commitments": (i32, [vp, vp, vp]),
         "amdzk_create_proof": (i32, [vp, vp, C.POINTER(vp), C.POINTER(sz), vp, sz, C.c_uint64, vp, sz, C.POINTER(sz)]),

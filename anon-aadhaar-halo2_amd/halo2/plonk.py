@@ -325,9 +325,10 @@ def flatten_circuit(desc):
 class ProvingKey:
     """plonk::keygen::{keygen_vk, keygen_pk} result, resident on the device."""
 
-    def __init__(self, ctx, params, desc, fixed_values, mapping, transcript_repr):
+    def __init__(self, ctx, params, desc, fixed_values, mapping, transcript_repr, flags=None):
         """fixed_values: (num_fixed, n, 4) uint64 Montgomery; mapping: Assembly.mapping;
-        transcript_repr: (4,) uint64 Montgomery Fr."""
+        transcript_repr: (4,) uint64 Montgomery Fr. flags: None = amdzk_keygen (the key's modes from the environment),
+        else amdzk_keygen_ex with KEYGEN_FULL_COSETS / KEYGEN_SERIAL or'ed together."""
         self.ctx, self.params, self.desc = ctx, params, desc
         n = 1 << desc["k"]
         cc, keep = flatten_circuit(desc)
@@ -335,8 +336,12 @@ class ProvingKey:
         mp = np.ascontiguousarray(np.array(mapping, dtype=np.uint32).reshape(-1, n, 2)) if len(desc["permutation_columns"]) else np.zeros((0, n, 2), np.uint32)
         tr = np.ascontiguousarray(transcript_repr, dtype=np.uint64).reshape(4)
         h = C.c_void_p()
-        ctx._chk(ctx.L.amdzk_keygen(ctx.h, params.h, C.byref(cc), fv.ctypes.data if fv.size else None,
-                                    mp.ctypes.data if mp.size else None, tr.ctypes.data, C.byref(h)))
+        if flags is None:
+            ctx._chk(ctx.L.amdzk_keygen(ctx.h, params.h, C.byref(cc), fv.ctypes.data if fv.size else None,
+                                        mp.ctypes.data if mp.size else None, tr.ctypes.data, C.byref(h)))
+        else:
+            ctx._chk(ctx.L.amdzk_keygen_ex(ctx.h, params.h, C.byref(cc), fv.ctypes.data if fv.size else None,
+                                           mp.ctypes.data if mp.size else None, tr.ctypes.data, int(flags), C.byref(h)))
         self.h = h
         del keep
 
@@ -380,6 +385,7 @@ class ProvingKey:
             self.h = None
 
 
+KEYGEN_FULL_COSETS, KEYGEN_SERIAL = 1, 2  # include/amdzk.h AMDZK_KEYGEN_*
 TRANSCRIPT_BLAKE2B, TRANSCRIPT_KECCAK256_EVM = 0, 1
 MULTIOPEN_GWC = 0x100  # OR into `transcript`: poly::kzg::multiopen::ProverGWC instead of ProverSHPLONK
 

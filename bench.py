@@ -9,8 +9,9 @@ extended_k = 17 — plus the IdentityCircuit / TimestampCircuit / SquareCircuit 
 permutation columns; --shape k15 / k18 = the RSA-SHA256 sub-circuit alone; the shapes live in
 anon-aadhaar-halo2_amd/workloads.py), on synthetic satisfying witnesses that are already resident in HBM when the
 timed region starts. Each step draws fresh blinding (seed = step index), takes the next of the
-resident witnesses and recomputes everything: 248 MSMs, 244 iNTTs, 244 coset NTTs, the h(X) evaluation over 2^17
-rows, 58+24 grand products, ~900 evaluations, SHPLONK. Witness synthesis (the reference's Rust chips) and keygen are
+resident witnesses and recomputes everything: 278 commitments (multi-scalar multiplications, in 8 batches), 274 inverse
+transforms, 274 x 3 coset transforms, the h(X) numerator on 3 cosets of 2^15 rows, 59 + 24 grand products, ~900
+evaluations, SHPLONK. Witness synthesis (the reference's Rust chips) and keygen are
 outside the step, as in upstream's own split. The SRS is a real one (g[i] = s^i G, g_lagrange[i] = L_i(s) G, built on
 the device), so the proofs are valid; tests/test_gpu_prover.py verifies this circuit's proof with the oracle's verifier.
 
@@ -19,6 +20,11 @@ touches HIP); under `python -m torch.distributed.run --nproc-per-node N bench.py
 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment). N > 1: independent proofs, one shard per GPU (weak
 scaling); the only collective is the gather of the finished proof bytes (fixed length), an RCCL all_gather.
 `--batch B` is BASELINE config 4: B independent witnesses (seeds 0..B-1), proof i on rank i mod N, gathered on all ranks.
+
+The timed region runs `--regions` times (5 by default: same steps, fresh blinding seeds); `value` and `ms_per_step` are
+those of the MEDIAN region and `config.value_samples` lists them all. `config.host_cpu_s_per_proof` is the process's CPU
+time over that region divided by its proofs (all host threads: the per-proof drivers that block on the GPU), and
+`--host-cores N` confines the rank to N cores before anything touches the GPU (one GPU's share of an 8-GPU host).
 
 After the timed region every rank repeats the steps with one host->device witness upload per proof (pinned memory,
 copy stream, double-buffered per in-flight context: anon-aadhaar-halo2_amd/feeder.py) and the line reports that
@@ -60,8 +66,13 @@ def parse_args(argv=None):
                          "one of 5, 4, 3, else 8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stream-pass", action="store_true", help="skip the PCIe-inclusive pass (one witness upload per proof)")
-    ap.add_argument("--no-merged-latency", action="store_true",
-                    help="skip the single-proof latency in the key's merged-commitments mode (one more keygen and two proofs; tools/profile_gpu.sh)")
+    ap.add_argument("--no-serial-latency", action="store_true",
+                    help="skip the single-proof latency of a key made with AMDZK_KEYGEN_SERIAL (one stream per proof, as in rounds 1-2; "
+                         "one more keygen and a few proofs; tools/profile_gpu.sh)")
+    ap.add_argument("--regions", type=int, default=5, help="how many times the timed region (--steps proofs per GPU) runs; the median is reported")
+    ap.add_argument("--host-cores", type=int, default=0,
+                    help="confine this rank to the first N cores of its affinity mask (sched_setaffinity before any GPU call); 0 = leave it alone")
+    ap.add_argument("--no-k22", action="store_true", help="skip BASELINE config 5 (2^22-point MSM and NTT, config.k22_stress) and the CPU kernel baselines")
     return ap.parse_args(argv)
 
 
@@ -173,31 +184,30 @@ class GpuProver:
     def prove(self, w, wi, seed):
         return self.plonk.create_proof(self.ctxs[w], self.pks[w], self.inst[wi], self.d_adv[wi], seed=seed)
 
-    def latency_with_merged_commitments(self, reference_proof, seed):
-        """One proof in flight, with a key made under AMDZK_MERGE_COMMITS=1 (read at keygen): the permutation products,
-        the lookup products and the random polynomial in ONE multi-scalar multiplication. The library's default keeps
-        them apart because that proves more per second with many proofs in flight; a host that runs one proof at a
-        time sets the variable. Same bytes, or the run fails."""
-        old = os.environ.get("AMDZK_MERGE_COMMITS")
-        os.environ["AMDZK_MERGE_COMMITS"] = "1"
-        try:
-            fixed_host = self.to_mont_dev(self.circuit.fixed).cpu().numpy().view(self.np.uint64)
-            pk = self.plonk.ProvingKey(self.ctx, self.params, self.desc, fixed_host, self.circuit.assembly.mapping, mont_limbs(self.tr_int))
-        finally:
-            if old is None:
-                del os.environ["AMDZK_MERGE_COMMITS"]
-            else:
-                os.environ["AMDZK_MERGE_COMMITS"] = old
-        try:
-            self.plonk.create_proof(self.ctx, pk, self.inst[0], self.d_adv[0], seed=seed + 1)  # workspaces in steady state
+    def latency(self, seed, reps=3, pk=None):
+        """One proof alone on the GPU, `reps` times: (median ms, the last proof)."""
+        pk = pk or self.pks[0]
+        ms = []
+        for r in range(reps):
             self.ctx.sync()
             t = time.perf_counter()
             proof = self.plonk.create_proof(self.ctx, pk, self.inst[0], self.d_adv[0], seed=seed)
-            ms = (time.perf_counter() - t) * 1e3
+            ms.append((time.perf_counter() - t) * 1e3)
+        return sorted(ms)[len(ms) // 2], proof
+
+    def latency_serial_key(self, reference_proof, seed):
+        """The same with a key made with AMDZK_KEYGEN_SERIAL: one proof's kernels on ONE stream, strictly one after
+        another (what every key did in rounds 1-2). Same bytes, or the run fails."""
+        fixed_host = self.to_mont_dev(self.circuit.fixed).cpu().numpy().view(self.np.uint64)
+        pk = self.plonk.ProvingKey(self.ctx, self.params, self.desc, fixed_host, self.circuit.assembly.mapping, mont_limbs(self.tr_int),
+                                   flags=self.plonk.KEYGEN_SERIAL)
+        try:
+            self.plonk.create_proof(self.ctx, pk, self.inst[0], self.d_adv[0], seed=seed + 1)  # workspaces in steady state
+            ms, proof = self.latency(seed, pk=pk)
         finally:
             pk.free()
         if proof != reference_proof:
-            raise SystemExit("bench.py: the proof made with merged commitments differs from the default mode's")
+            raise SystemExit("bench.py: the proof of the serial-mode key differs from the default (lanes) key's")
         return ms
 
     def sync(self):
@@ -316,6 +326,11 @@ def run_rank(args):
     # proofs in flight than queues, kernels of different proofs queue up behind each other. Must be set before the
     # runtime initialises (libamdzk.so's own initialiser does the same for hosts that load it first).
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    cores_allowed = None
+    if hasattr(os, "sched_getaffinity"):
+        if args.host_cores > 0:  # before torch / HIP: no exec, no taskset hop; threads started later inherit the mask
+            os.sched_setaffinity(0, sorted(os.sched_getaffinity(0))[:args.host_cores])
+        cores_allowed = len(os.sched_getaffinity(0))
     import torch
     import torch.distributed as dist
 
@@ -381,11 +396,20 @@ def run_rank(args):
 
     run_pool(P, list(range(P)), warm_context)
     prover.check_affinity()
-    barrier()
-    t0 = time.perf_counter()
-    proofs = run_pool(P, jobs, lambda w, j: prover.prove(w, j[0], j[1]))
-    barrier()
-    dt = max_over_ranks(time.perf_counter() - t0)
+    # the timed region, R times over: same steps, fresh blinding seeds; region 0's proofs are the ones gathered and
+    # compared with the streamed pass. Reported: the median region.
+    regions, proofs = [], None
+    for reg in range(max(1, args.regions)):
+        jobs_r = [(wi, seed + 100000 * reg) for wi, seed in jobs]
+        barrier()
+        c0 = time.process_time()
+        t0 = time.perf_counter()
+        pr = run_pool(P, jobs_r, lambda w, j: prover.prove(w, j[0], j[1]))
+        barrier()
+        regions.append((max_over_ranks(time.perf_counter() - t0), time.process_time() - c0))
+        if reg == 0:
+            proofs = pr
+    dt, host_cpu_s = sorted(regions)[len(regions) // 2]
     gathered_ok = None
     if world > 1:
         # the one exchange step: every rank's proofs (equal length) gathered on all ranks (RCCL all_gather)
@@ -421,19 +445,21 @@ def run_rank(args):
             raise SystemExit("bench.py: proofs from streamed witnesses differ from the resident-witness proofs")
 
     roof = cpu = None
-    wall_prof = lat_ms = lat_merged_ms = None
+    wall_prof = lat_ms = lat_serial_ms = k22 = None
     if rank == 0 and not stub:
         roof, wall_prof = roofline(prover, desc)
-        # single-proof latency: one proof alone on the GPU, no per-kernel events; then the same with the key in its
-        # latency mode (merged commitments), whose proof must be the same bytes
+        # single-proof latency: one proof alone on the GPU, no per-kernel events (median of 3); then the same with a
+        # serial-mode key (one stream), whose proof must be the same bytes
         prover.sync()
-        t_l = time.perf_counter()
-        ref = prover.prove(0, 0, 777001)
-        lat_ms = (time.perf_counter() - t_l) * 1e3
-        lat_merged_ms = None if args.no_merged_latency else prover.latency_with_merged_commitments(ref, 777001)
+        lat_ms, ref = prover.latency(777001)
+        lat_serial_ms = None if args.no_serial_latency else prover.latency_serial_key(ref, 777001)
+        if not args.no_k22:
+            k22 = k22_stress(prover, want_cpu=not args.no_cpu_baseline)
         if not args.no_cpu_baseline:
             gpu_proof = prover.prove(0, 0, 424242)
             cpu = cpu_baseline(prover, gpu_proof)
+            if k22 and k22.get("cpu_kernels"):
+                cpu["kernels"] = k22.pop("cpu_kernels")
 
     if rank == 0:
         ms = dt / steps * 1e3
@@ -449,14 +475,21 @@ def run_rank(args):
                                        "KZG/SHPLONK/Blake2b, %d distinct witnesses per GPU resident in HBM"
                                        % (args.shape, desc["num_advice"], len(desc["lookups"]), len(desc["permutation_columns"]),
                                           desc["cs_degree"], nw),
-                           "k": prover.K, "extended_k": prover.K + 2, "proof_bytes": len(proofs[-1]), "proofs_in_flight_per_gpu": P,
+                           "k": prover.K, "extended_k": prover.K + max(0, (desc["cs_degree"] - 2).bit_length()),
+                           "proof_bytes": len(proofs[-1]), "proofs_in_flight_per_gpu": P,
                            "batch": args.batch or None, "proofs_total": world * steps,
                            "warmup_proofs_untimed": max(args.warmup, 0) * P,
+                           "value_samples": [round(world * steps / r[0], 4) for r in regions],
+                           "timed_regions": len(regions),
+                           "host_cpu_s_per_proof": round(host_cpu_s / steps, 5), "host_threads": min(P, steps) + 1,
+                           "host_cores_allowed": cores_allowed,
+                           "host_note": "rank 0's process CPU time (all threads) over the median region / its proofs; one host thread "
+                                        "per proof in flight, blocked in the HIP runtime while the GPU works",
                            "single_proof_latency_ms": round(lat_ms, 3) if lat_ms else None,
-                           "single_proof_latency_ms_merged_commitments": round(lat_merged_ms, 3) if lat_merged_ms else None,
-                           "latency_note": "one proof in flight; merged = key made under AMDZK_MERGE_COMMITS=1 (three commitment batches in "
-                                           "one multi-scalar multiplication: shorter alone, 1.6 % fewer proofs/s with a dozen in flight, "
-                                           "so not the default); same proof bytes",
+                           "single_proof_latency_ms_serial_key": round(lat_serial_ms, 3) if lat_serial_ms else None,
+                           "latency_note": "one proof in flight, median of 3; default key = the proof's independent work on three "
+                                           "streams (lanes), serial key (AMDZK_KEYGEN_SERIAL) = one stream; same proof bytes",
+                           "k22_stress": k22,
                            "pcie_inclusive_proofs_per_s": round(stream_rate, 4) if stream_rate else None,
                            "pcie_inclusive_note": "same steps with one %.0f MiB witness upload per proof from pinned host memory on a copy "
                                                   "stream, double-buffered per in-flight context; proofs byte-equal to the resident run"
@@ -505,7 +538,8 @@ def roofline(prover, desc):
     roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(alg_bytes / avg_s / 1e9, 3), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(alg_bytes / avg_s / 1e9 / HBM_PEAK_GBS, 6), "traffic": pmc.get("traffic"),
             "traffic_source": pmc.get("source"), "algorithmic_bytes_per_launch": round(alg_bytes),
-            "avg_launch_ms": round(total_ms / launches, 4), "launches_per_step": launches,
+            "avg_launch_ms": round(total_ms / launches, 4), "avg_launch_ms_profile": pmc.get("avg_ms_profile"),
+            "launches_per_step": launches,
             # what the kernel is actually limited by: VALU issue. cycles per VALU wave-instruction =
             # launch time x 1024 SIMDs x 2.4 GHz / SQ_INSTS_VALU per launch; ~5 means the SIMDs issue back to back
             # (v_mad_u64_u32 issues at 4.3 cycles at best, plain 32-bit VALU at 2.5-4.2: profiles/r02k_instruction_rates_mb_isa.jsonl)
@@ -535,16 +569,44 @@ def issue_bound(pmc, avg_s):
             "mad_issue_ms_per_launch": round(model_s * 1e3, 4), "frac": round(model_s / avg_s, 4)}
 
 
+def strip_comments(text):
+    """C/C++ source without comments and with runs of blanks collapsed (string and character literals kept as they are),
+    so that editing a comment does not change kernel_src_hash()."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c in "\"'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            while i < n and text[i] != "\n":
+                i += 1
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c)
+            i += 1
+    lines = [" ".join(ln.split()) for ln in "".join(out).split("\n")]
+    return "\n".join(ln for ln in lines if ln)
+
+
 def kernel_src_hash():
-    """sha256 over the kernel sources (csrc/*.hip, *.cuh, *.hpp, *.inc and the Makefile with its flags), the same way tools/summarize_prof.py stamps a PMC
-    summary: counters measured on other kernel code are not this build's counters."""
+    """sha256 over the kernel sources (csrc/*.hip, *.cuh, *.hpp, *.inc, comments and blank space stripped, and the Makefile
+    with its flags), the same way tools/summarize_prof.py stamps a PMC summary: counters measured on other kernel code
+    are not this build's counters, and a comment edit is not other kernel code."""
     import glob
     h = hashlib.sha256()
     d = os.path.join(ROOT, "anon-aadhaar-halo2_amd", "csrc")
     for p in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.cuh")) + glob.glob(os.path.join(d, "*.hpp")) +
                     glob.glob(os.path.join(d, "*.inc")) + [os.path.join(d, "Makefile")]):
         h.update(os.path.basename(p).encode() + b"\0")
-        h.update(open(p, "rb").read())
+        text = open(p, "r", errors="replace").read()
+        h.update((text if p.endswith("Makefile") else strip_comments(text)).encode())
     return h.hexdigest()[:16]
 
 
@@ -585,10 +647,120 @@ def pmc_counters(kernel):
                             out["valu"] = round(float(row["SQ_INSTS_VALU_per_launch"]))
                         if mad_share is not None and kernel == "msm_accum_l1":
                             out["mad_share"] = mad_share
+                        out["avg_ms_profile"] = steady_avg_ms(path, names.get(kernel, kernel))
                         return out
         except OSError:
             continue
     return {"source": "none for kernel sources %s%s" % (want, " (newest stamped summary, %s, is of other sources: refused)" % stale if stale else "")}
+
+
+def k22_stress(prover, want_cpu):
+    """BASELINE config 5: one 2^22-point BN254 G1 multi-scalar multiplication (uniform scalars; then 50 % zero / 25 %
+    below 2^64) and one 2^22 Fr transform forward + inverse on resident inputs, with their fractions of the 8 TB/s HBM
+    peak on algorithmic bytes (96 n and 64 n). With the CPU leg: the same kernels through the oracle
+    (liboracle.so: Pippenger as halo2's best_multiexp, radix-2 best_fft; OpenMP on the box's host threads) at 2^15,
+    2^18 and 2^22 — and the 2^22 results of both sides must be equal."""
+    import ctypes
+    np, torch, pkg, ctx = prover.np, prover.torch, prover.pkg, prover.ctx
+    k, n = 22, 1 << 22
+    s_int = 7 ** 20 % R  # BASELINE.md §3: tau from "seed 7"
+    t0 = time.perf_counter()
+    params = pkg.kzg.ParamsKZG.setup(ctx, k, mont_limbs(s_int), want_host_copy=want_cpu)
+    ctx.sync()
+    out = {"k": k, "srs_setup_s": round(time.perf_counter() - t0, 2)}
+
+    class V:
+        def __init__(self, t):
+            self.ptr = ctypes.c_void_p(t.data_ptr())
+
+    g = torch.Generator(device="cuda")
+    g.manual_seed(42)
+    uni = torch.randint(0, 2 ** 62, (n, 4), dtype=torch.int64, device="cuda", generator=g)
+    uni[:, 3] >>= 2  # any 252-bit pattern is a valid Montgomery representative
+    sel = torch.randint(0, 4, (n,), device="cuda", generator=g)
+    skew = uni.clone()
+    skew[sel < 2] = 0
+    skew[sel == 2, 1:] = 0
+    ctx._chk(ctx.L.amdzk_fr_from_raw_dev(ctx.h, skew.data_ptr(), n))
+    ctx.sync()
+    torch.cuda.synchronize()
+
+    def med(fn, reps):
+        fn()
+        ts = []
+        for _ in range(reps):
+            ctx.timer_start()
+            fn()
+            ts.append(ctx.timer_stop())
+        return float(np.median(ts))
+
+    gpu_msm = None
+    for name, col in (("msm", uni), ("msm_skewed", skew)):
+        res = []
+        ms = med(lambda: res.append(pkg.arithmetic.best_multiexp_dev(ctx, params.h, 0, V(col), 1, n)), 3)
+        if name == "msm":
+            gpu_msm = res[-1][0]
+        out[name + "_ms"] = round(ms, 3)
+        out[name + "_frac_of_8TBps"] = round(96.0 * n / ms / 1e6 / HBM_PEAK_GBS, 5)
+    dom = pkg.domain.EvaluationDomain(ctx, 3, k)
+    a = uni.clone()
+    for name, w, flags in (("ntt", dom.omega, 0), ("intt", dom.omega_inv, 1)):
+        ms = med(lambda: pkg.arithmetic.best_fft_dev(ctx, V(a), w, k, flags=flags), 5)
+        out[name + "_ms"] = round(ms, 3)
+        out[name + "_frac_of_8TBps"] = round(64.0 * n / ms / 1e6 / HBM_PEAK_GBS, 5)
+    out["note"] = "resident inputs, HIP-event timed, medians; fractions on algorithmic bytes (96 n per MSM, 64 n per transform)"
+    if want_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import plonk_fast as PF
+
+        L, th = PF.lib(), PF.threads()
+        vp = lambda arr: arr.ctypes.data_as(ctypes.c_void_p)
+        scal = np.ascontiguousarray(uni.cpu().numpy().view(np.uint64))
+        bases = params._g
+        kern = {"cores": th, "note": "liboracle.so (C++/OpenMP restatement of best_multiexp / best_fft), one run each, on the first 2^k "
+                                     "scalars and SRS points of the 2^22 stress inputs"}
+        for kk in (15, 18, 22):
+            m = 1 << kk
+            res = np.zeros(8, np.uint64)
+            t0 = time.perf_counter()
+            L.oracle_best_multiexp(vp(scal), vp(bases), ctypes.c_size_t(m), ctypes.c_int(th), vp(res))
+            kern["msm_2^%d_ms" % kk] = round((time.perf_counter() - t0) * 1e3, 2)
+            if kk == k:
+                jac = gpu_msm.reshape(12)
+                kern["msm_2^22_equal_gpu"] = bool(jac[8:].any()) and bool((jac[:8] == res).all())
+            w = np.zeros(4, np.uint64)
+            L.oracle_fr_omega(ctypes.c_uint32(kk), vp(w))
+            v = np.ascontiguousarray(scal[:m].copy())
+            t0 = time.perf_counter()
+            L.oracle_best_fft(vp(v), vp(w), ctypes.c_uint32(kk), ctypes.c_int(th))
+            kern["ntt_2^%d_ms" % kk] = round((time.perf_counter() - t0) * 1e3, 2)
+            if kk == k:
+                b = uni.clone()
+                pkg.arithmetic.best_fft_dev(ctx, V(b), w, k)
+                ctx.sync()
+                kern["ntt_2^22_equal_gpu"] = bool((b.cpu().numpy().view(np.uint64) == v).all())
+        out["cpu_kernels"] = kern
+        if not (kern["msm_2^22_equal_gpu"] and kern["ntt_2^22_equal_gpu"]):
+            raise SystemExit("bench.py: the 2^22 stress results of the GPU and of the CPU oracle differ: %r" % kern)
+    dom.free()
+    params.free()
+    return out
+
+
+def steady_avg_ms(summary_path, kernel):
+    """Average launch time of `kernel` over ONE steady-state proof of the rocprofv3 --kernel-trace pass that belongs to a
+    PMC summary (profiles/<tag>_kernel_stats_steady.csv, written by tools/summarize_prof.py next to it)."""
+    import csv
+    path = summary_path.replace("_kernel_summary.csv", "_kernel_stats_steady.csv")
+    try:
+        with open(path) as f:
+            rows = [ln for ln in f if not ln.startswith("#")]
+        for row in csv.DictReader(rows):
+            if row["kernel"] == kernel:
+                return round(float(row["avg_ms"]), 4)
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def cpu_baseline(prover, gpu_proof):

@@ -217,6 +217,18 @@ typedef struct amdzk_pk amdzk_pk;
 int amdzk_keygen(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* circuit,
                  const uint64_t* fixed_values, const uint32_t* perm_mapping,
                  const uint64_t transcript_repr[4], amdzk_pk** out);
+/* The same with the key's modes as explicit flags (amdzk_keygen takes them from the environment: AMDZK_FULL_COSETS=1,
+ * AMDZK_SERIAL=1), so that two keys of one process can differ:
+ *   AMDZK_KEYGEN_FULL_COSETS  evaluate the quotient numerator on all 2^(extended_k - k) cosets of upstream's extended
+ *                             domain instead of cs_degree - 1 of them: upstream's own computation, byte-identical
+ *                             also for witnesses that do NOT satisfy the circuit (satisfying ones are identical either way)
+ *   AMDZK_KEYGEN_SERIAL       one proof's kernels on the caller's stream only, strictly one after another (no lanes:
+ *                             see amdzk_create_proof) */
+#define AMDZK_KEYGEN_FULL_COSETS 1u
+#define AMDZK_KEYGEN_SERIAL 2u
+int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* circuit,
+                    const uint64_t* fixed_values, const uint32_t* perm_mapping,
+                    const uint64_t transcript_repr[4], uint32_t flags, amdzk_pk** out);
 void amdzk_pk_free(amdzk_ctx* ctx, amdzk_pk* pk);
 int amdzk_pk_check_affinity(amdzk_ctx* ctx, const amdzk_pk* pk);
 /* VerifyingKey commitments: fixed columns (num_fixed x G1Affine), permutation (num_perm_columns x G1Affine). */

@@ -57,6 +57,42 @@ def square_circuit(plonk, k=4, signal=5):
     return c
 
 
+def high_degree_circuit(plonk, k=5, power=9, seed=1):
+    """One gate s * (b - a^power): constraint degree power + 1 (10 by default, i.e. 9 quotient pieces and 9 cosets —
+    more than the 8 the templated recombination kernel covers), with copy constraints so that the permutation
+    argument's chunks (degree - 2 columns per grand product) are exercised at that degree too."""
+    rnd = np.random.RandomState(seed)
+    cs = plonk.ConstraintSystem()
+    a, b = cs.advice_column(), cs.advice_column()
+    sel = cs.selector()
+    cs.enable_equality(a)
+    cs.enable_equality(b)
+
+    def gate(meta):
+        s = meta.query_selector(sel)
+        x = meta.query_advice(a, 0)
+        p = x
+        for _ in range(power - 1):
+            p = p * x
+        return [s * (meta.query_advice(b, 0) - p)]
+
+    cs.create_gate(gate)
+    c = Circuit(cs, k)
+    c.assembly = plonk.Assembly(c.n, len(cs.permutation_columns))
+    for row in range(c.usable):
+        x = int(rnd.randint(1, 1 << 30))
+        c.fixed[sel.index][row] = 1
+        c.advice[a.index][row] = x
+        c.advice[b.index][row] = pow(x, power, R)
+    c.advice[a.index][5] = c.advice[a.index][2]
+    c.advice[b.index][5] = c.advice[b.index][2]
+    c.copy(a, 2, a, 5)
+    c.copy(b, 2, b, 5)
+    c.instances = []
+    check_satisfied(c)
+    return c
+
+
 def lookup_circuit(plonk, k=5, seed=1):
     rnd = np.random.RandomState(seed)
     cs = plonk.ConstraintSystem()

@@ -26,13 +26,13 @@ def plonk(pkg):
 _srs_cache = {}
 
 
-def setup(ctx, pkg, plonk, oracle, c, transcript_repr_int=123456789):
+def setup(ctx, pkg, plonk, oracle, c, transcript_repr_int=123456789, flags=None):
     if c.k not in _srs_cache:
         _srs_cache[c.k] = zu.test_srs(oracle, c.k, TAU)
     g, gl = _srs_cache[c.k]
     params = pkg.kzg.ParamsKZG(ctx, c.k, g=g, g_lagrange=gl)
     fixed = np.stack([zu.ints_to_fr(oracle, col) for col in c.fixed]) if c.fixed else np.zeros((0, c.n, 4), np.uint64)
-    pk = plonk.ProvingKey(ctx, params, c.desc, fixed, c.assembly.mapping, zu.fr_from_int(transcript_repr_int))
+    pk = plonk.ProvingKey(ctx, params, c.desc, fixed, c.assembly.mapping, zu.fr_from_int(transcript_repr_int), flags=flags)
     adv = np.stack([zu.ints_to_fr(oracle, col) for col in c.advice])
     d_adv = ctx.alloc(adv.nbytes).upload(adv)
     inst = [zu.ints_to_fr(oracle, col) if col else np.zeros((0, 4), np.uint64) for col in c.instances]
@@ -107,28 +107,50 @@ def test_quotient_coset_modes(ctx, pkg, plonk, oracle, monkeypatch):
             PR.verify_proof(opk, bad.instances, proofs[(mode, "bad")])
 
 
-def test_merged_commitments_mode_gives_the_same_bytes(ctx, pkg, plonk, oracle, monkeypatch):
-    """AMDZK_MERGE_COMMITS=1 (read at keygen): the permutation products, the lookup products and the random polynomial —
-    the latter as its Lagrange values under g_lagrange instead of its coefficients under g — are committed by one
-    multi-scalar multiplication. Same group elements, same transcript order: the proof bytes must not change
-    (SHPLONK and GWC; circuits with lookups and permutations, and the reference's SquareCircuit with neither lookups nor a second permutation set)."""
+def test_lanes_and_serial_mode_give_the_same_bytes(ctx, pkg, plonk, oracle):
+    """create_proof spreads one proof over three streams (lanes: the coset transforms of a phase, the lookup products
+    and the random polynomial run beside the commitments the transcript waits for). A key made with
+    AMDZK_KEYGEN_SERIAL keeps everything on the caller's stream. Only the order of transcript writes is fixed by
+    upstream, so the bytes must be the same — for SHPLONK and GWC, for circuits with lookups and permutations and for
+    the reference's SquareCircuit (no lookup, one permutation set), with proofs back to back on one key (the lanes
+    of proof i must be quiet before proof i + 1 reuses the workspace) and with the flag-selected full-coset mode."""
     shapes = [circuits.rsa_sha256_shape(plonk, k=7, num_advice=5, num_lookup_advice=2, lookup_bits=5, num_spread=2, spread_bits=3),
               circuits.lookup_circuit(plonk, 6, seed=9), circuits.square_circuit(plonk, 4, signal=5)]
     for c in shapes:
         got = {}
-        for mode in ("split", "merged"):
-            if mode == "merged":
-                monkeypatch.setenv("AMDZK_MERGE_COMMITS", "1")
-            else:
-                monkeypatch.delenv("AMDZK_MERGE_COMMITS", raising=False)
-            params, pk, d_adv, inst = setup(ctx, pkg, plonk, oracle, c)
+        for mode, flags in (("lanes", 0), ("serial", plonk.KEYGEN_SERIAL), ("serial_full", plonk.KEYGEN_SERIAL | plonk.KEYGEN_FULL_COSETS),
+                            ("lanes_full", plonk.KEYGEN_FULL_COSETS)):
+            params, pk, d_adv, inst = setup(ctx, pkg, plonk, oracle, c, flags=flags)
             got[mode] = [plonk.create_proof(ctx, pk, inst, d_adv, seed=33),
-                         plonk.create_proof(ctx, pk, inst, d_adv, seed=34, transcript=plonk.MULTIOPEN_GWC)]
+                         plonk.create_proof(ctx, pk, inst, d_adv, seed=34, transcript=plonk.MULTIOPEN_GWC),
+                         plonk.create_proof(ctx, pk, inst, d_adv, seed=33)]
             d_adv.free(); pk.free(); params.free()
-        monkeypatch.delenv("AMDZK_MERGE_COMMITS", raising=False)
-        assert got["split"] == got["merged"]
+        assert got["lanes"] == got["serial"] == got["serial_full"] == got["lanes_full"]
+        assert got["lanes"][0] == got["lanes"][2]
         opk = PR.keygen(c.desc, c.fixed, c.assembly.mapping, TAU, transcript_repr=123456789)
-        assert got["merged"][0] == PR.create_proof(opk, c.instances, c.advice, seed=33)
+        assert got["lanes"][0] == PR.create_proof(opk, c.instances, c.advice, seed=33)
+        assert got["lanes"][1] == PR.create_proof(opk, c.instances, c.advice, seed=34, multiopen="gwc")
+
+
+@pytest.mark.parametrize("power,flags", [(9, 0), (9, 1), (4, 0), (16, 0)])
+def test_high_degree_gate_bytes_equal_oracle(ctx, pkg, plonk, oracle, power, flags):
+    """Constraint degree 10 (9 quotient pieces: more cosets than the templated recombination kernel's 8 — the generic
+    kernel; ADVICE r2: keygen used to refuse it), the same in full-coset mode (16 cosets), degree 5 (4 cosets = the
+    whole extended domain) and degree 17 (16 pieces on 16 cosets): byte-equal to the oracle prover, and verified."""
+    c = circuits.high_degree_circuit(plonk, 5, power=power)
+    assert c.desc["cs_degree"] == power + 1
+    params, pk, d_adv, inst = setup(ctx, pkg, plonk, oracle, c, flags=flags)
+    got = plonk.create_proof(ctx, pk, inst, d_adv, seed=17)
+    opk = PR.keygen(c.desc, c.fixed, c.assembly.mapping, TAU, transcript_repr=123456789)
+    assert got == PR.create_proof(opk, c.instances, c.advice, seed=17)
+    assert PR.verify_proof(opk, c.instances, got)
+    d_adv.free(); pk.free(); params.free()
+
+
+def test_keygen_ex_rejects_unknown_flags(ctx, pkg, plonk, oracle):
+    c = circuits.square_circuit(plonk, 4, signal=5)
+    with pytest.raises(Exception):
+        setup(ctx, pkg, plonk, oracle, c, flags=0x80)
 
 
 def test_lookup_failure_is_reported(ctx, pkg, plonk, oracle):

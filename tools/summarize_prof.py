@@ -3,6 +3,11 @@
 ROCm 7.2 writes rocpd SQLite databases) into tracked files:
   profiles/<tag>_rocprofv3_kernel_stats.csv   rocprofv3 --kernel-trace --stats: calls, total / average ns, share
   profiles/<tag>_kernel_summary.csv           the same plus FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU per launch (--pmc passes)
+  profiles/<tag>_kernel_stats_steady.csv      the same trace cut down to ONE steady-state proof (the dispatches between the
+                                              last two random-polynomial kernels, one per proof, of a run whose keys are
+                                              serial — AMDZK_SERIAL=1 in tools/profile_gpu.sh — so that kernels do not
+                                              overlap): launches and average duration per kernel. avg x launches of the
+                                              dominant kernel is what bench.py's live HIP-event figure measures
   profiles/<tag>_valu_instruction_counts.txt  instruction totals per kernel and per proof
 The first line of the summary stamps the hash of the kernel sources the run was made with (bench.kernel_src_hash):
 bench.py uses a summary's counters only when that hash is its own build's.
@@ -67,7 +72,7 @@ def mad_share_of_hot_loop():
 
 def main():
     src, tag = sys.argv[1], sys.argv[2]
-    proofs = float(sys.argv[3]) if len(sys.argv) > 3 else 4.0  # warm-up + timed + the per-kernel-timed proof + the latency proof of bench.py
+    proofs = float(sys.argv[3]) if len(sys.argv) > 3 else 6.0  # warm-up + timed + the per-kernel-timed proof + the 3 latency proofs of bench.py
     os.makedirs("profiles", exist_ok=True)
     stats = collections.OrderedDict()
     c = db(src, "stats")
@@ -82,6 +87,22 @@ def main():
                 if k.startswith("at::") or "rocclr" in k or "elementwise" in k:
                     continue
                 stats[k] = (calls, avg / 1e6, 100.0 * tot / total)
+        # one steady-state proof: from the start of the last-but-one random-polynomial kernel (the first kernel of a
+        # proof) to the start of the last one
+        marks = [r[0] for r in c.execute("select start from kernels where name like '%chacha20_fr_random%' order by start")]
+        if len(marks) >= 2:
+            import bench as _b
+            a, b = marks[-2], marks[-1]
+            srows = c.execute("select name, count(*), sum(duration), avg(duration) from kernels where start >= ? and start < ? "
+                              "group by name order by sum(duration) desc", (a, b)).fetchall()
+            with open(os.path.join("profiles", tag + "_kernel_stats_steady.csv"), "w") as o:
+                o.write("# kernel_src_sha256=%s\n" % _b.kernel_src_hash())
+                o.write("# one steady-state proof of the rocprofv3 --kernel-trace pass (serial keys: no overlapping kernels), wall %.3f ms, "
+                        "sum of kernel durations %.3f ms\n" % ((b - a) / 1e6, sum(r[2] for r in srows) / 1e6))
+                o.write("kernel,launches,total_ms,avg_ms\n")
+                for name, calls, tot, avg in srows:
+                    o.write('"%s",%d,%.4f,%.4f\n' % (short(name), calls, tot / 1e6, avg / 1e6))
+            print(open(os.path.join("profiles", tag + "_kernel_stats_steady.csv")).read())
     pmc = {}
     per_counter = collections.defaultdict(lambda: collections.defaultdict(float))
     calls_insts = collections.Counter()
@@ -111,7 +132,7 @@ def main():
             a, b = marks[-2], marks[-1]
             one_proof = collections.Counter()
             for d, name, v in seq:
-                if a < d <= b:
+                if a <= d < b:  # the random-polynomial kernel is the first kernel of a proof
                     one_proof[short(name)] += v
     import bench
     path = os.path.join("profiles", tag + "_kernel_summary.csv")
@@ -135,7 +156,7 @@ def main():
         per_proof = sum(v.get("SQ_INSTS_VALU", 0) for k, v in per_counter.items() if k not in STARTUP)
         with open(os.path.join("profiles", tag + "_valu_instruction_counts.txt"), "w") as o:
             o.write("rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVES -- python3 bench.py --steps 1 --warmup 1 "
-                    "--concurrency 1 --no-cpu-baseline --no-stream-pass --no-merged-latency\n(shape full, k = 15, kernel sources %s; keygen + %.2f proofs)\n\n" % (bench.kernel_src_hash(), proofs))
+                    "--concurrency 1 --regions 1 --no-cpu-baseline --no-stream-pass --no-serial-latency --no-k22 (AMDZK_SERIAL=1)\n(shape full, k = 15, kernel sources %s; keygen + %.2f proofs)\n\n" % (bench.kernel_src_hash(), proofs))
             o.write("%-46s %6s %12s %10s %10s %10s %10s\n" % ("kernel", "calls", "VALU", "SALU", "LDS", "VMEM_RD", "waves"))
             for k, v in sorted(per_counter.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0))[:24]:
                 o.write("%-46s %6d %12.3e %10.2e %10.2e %10.2e %10.2e%s\n" % (k[:46], calls_insts[k], v.get("SQ_INSTS_VALU", 0), v.get("SQ_INSTS_SALU", 0),
