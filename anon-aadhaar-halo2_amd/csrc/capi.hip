@@ -4,6 +4,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "common.hpp"
 
 using namespace bn254;
@@ -102,6 +104,13 @@ int zk_ptr_on_device(amdzk_ctx* ctx, const void* p, const char* what) {
   return AMDZK_OK;
 }
 
+// Every stream of the library is a plain non-blocking stream. (Measured and rejected: hipStreamCreateWithPriority —
+// the caller's stream at the device's highest priority, the lanes at its lowest, so that the commitment chain's
+// latency-bound kernels would not queue behind a chip-filling transform — made EVERYTHING slower on this runtime:
+// 56 ms instead of 21 for one proof, 57 instead of 72 proofs/s with ten in flight, 39 ms even for a serial-mode key;
+// profiles/r03b_stream_priorities_and_gating.txt.)
+hipError_t zk_stream_create(hipStream_t* s, bool /*lane*/) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+
 int zk_lane(amdzk_ctx* ctx, int i, amdzk_ctx** out) {
   if (i < 0 || i >= amdzk_ctx::MAX_LANES) ZK_FAIL(ctx, AMDZK_E_INVALID, "lane %d out of range", i);
   if (ctx->prof || ctx->parent) {  // profiling: one stream; a lane has no lanes of its own
@@ -113,7 +122,7 @@ int zk_lane(amdzk_ctx* ctx, int i, amdzk_ctx** out) {
     l->device = ctx->device;
     l->num_cu = ctx->num_cu;
     l->parent = ctx;
-    if (hipStreamCreateWithFlags(&l->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    if (zk_stream_create(&l->own_stream, true) != hipSuccess) {
       delete l;
       ZK_FAIL(ctx, AMDZK_E_HIP, "lane %d: hipStreamCreate failed", i);
     }
@@ -133,11 +142,21 @@ int zk_stream_after(amdzk_ctx* waiter, amdzk_ctx* signaler) {
   return AMDZK_OK;
 }
 
+int zk_stream_after_l1(amdzk_ctx* waiter, amdzk_ctx* signaler) {
+  if (waiter == signaler || waiter->stream == signaler->stream || !signaler->msm_l1_evt) return AMDZK_OK;
+  ZK_HIP(waiter, hipStreamWaitEvent(waiter->stream, signaler->msm_l1_evt, 0));
+  return AMDZK_OK;
+}
+
 int zk_sync_all(amdzk_ctx* ctx) {
   amdzk_ctx* root = ctx->parent ? ctx->parent : ctx;
   ZK_HIP(ctx, hipStreamSynchronize(root->stream));
+  if (root->msm_stream) ZK_HIP(ctx, hipStreamSynchronize(root->msm_stream));
   for (amdzk_ctx* l : root->lanes)
-    if (l) ZK_HIP(ctx, hipStreamSynchronize(l->stream));
+    if (l) {
+      ZK_HIP(ctx, hipStreamSynchronize(l->stream));
+      if (l->msm_stream) ZK_HIP(ctx, hipStreamSynchronize(l->msm_stream));
+    }
   return AMDZK_OK;
 }
 
@@ -151,6 +170,13 @@ static void ctx_release(amdzk_ctx* ctx) {
   for (auto e : ctx->evt_pool) hipEventDestroy(e);
   for (auto e : ctx->order_evt)
     if (e) hipEventDestroy(e);
+  for (auto e : ctx->msm_evt)
+    if (e) hipEventDestroy(e);
+  if (ctx->msm_l1_evt) hipEventDestroy(ctx->msm_l1_evt);
+  if (ctx->msm_stream) {
+    hipStreamSynchronize(ctx->msm_stream);
+    hipStreamDestroy(ctx->msm_stream);
+  }
   if (ctx->t0) hipEventDestroy(ctx->t0);
   if (ctx->t1) hipEventDestroy(ctx->t1);
   if (ctx->copy_stream) {
@@ -173,6 +199,22 @@ struct HwQueuesDefault {
 } hw_queues_default;
 }  // namespace
 
+// Contexts alive in this process, against the hardware queues the HIP runtime was (most likely) initialised with: more
+// proofs in flight than queues queue up behind each other silently (6-9 % fewer proofs per second with 8-12 in flight on
+// the default 4), e.g. when the host initialised HIP before this library could set the variable. Said once, on stderr.
+static std::atomic<int> g_live_contexts{0};
+static std::atomic<bool> g_queue_note_given{false};
+static void note_context_created() {
+  const char* e = getenv("GPU_MAX_HW_QUEUES");
+  const int queues = e && atoi(e) > 0 ? atoi(e) : 4;
+  const int live = ++g_live_contexts;
+  if (live > queues && !g_queue_note_given.exchange(true))
+    fprintf(stderr,
+            "[amdzk] note: %d contexts in this process but GPU_MAX_HW_QUEUES=%d hardware queues: kernels of different contexts will wait "
+            "for each other. Export GPU_MAX_HW_QUEUES >= the number of proofs in flight before the process's first HIP call.\n",
+            live, queues);
+}
+
 extern "C" {
 
 int amdzk_version(void) { return 1000; }
@@ -194,13 +236,14 @@ int amdzk_init(int device_id, amdzk_ctx** out) {
   amdzk_ctx* c = new amdzk_ctx();
   c->device = device_id;
   c->num_cu = prop.multiProcessorCount;
-  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+  if (zk_stream_create(&c->own_stream, false) != hipSuccess) {
     delete c;
     return AMDZK_E_HIP;
   }
   c->stream = c->own_stream;
   hipEventCreate(&c->t0);
   hipEventCreate(&c->t1);
+  note_context_created();
   *out = c;
   return AMDZK_OK;
 }
@@ -214,6 +257,7 @@ void amdzk_destroy(amdzk_ctx* ctx) {
       l = nullptr;
     }
   ctx_release(ctx);
+  --g_live_contexts;
 }
 
 const char* amdzk_last_error(const amdzk_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }

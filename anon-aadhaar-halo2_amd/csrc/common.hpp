@@ -72,6 +72,15 @@ struct amdzk_ctx {
   amdzk_ctx* parent = nullptr;
   hipEvent_t order_evt[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   unsigned order_next = 0;
+  // Pipelined commitments (msm.hip zk_msm_dev_xyzz): a batch's column groups alternate between `stream` and this
+  // second stream, level-1 kernels chained through msm_evt[0..5]; [6] / [7] order the two streams at entry / exit.
+  bool msm_pipeline = false;
+  hipStream_t msm_stream = nullptr;
+  hipEvent_t msm_evt[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // recorded behind the (last) level-1 kernel of every commitment batch on this ctx: what follows on ANOTHER stream and
+  // would only compete with that chip-filling kernel waits for it (zk_stream_after_l1) and then runs beside the batch's
+  // latency-bound tail instead
+  hipEvent_t msm_l1_evt = nullptr;
 };
 
 #define ZK_FAIL(ctx, code, ...)                         \
@@ -128,9 +137,12 @@ hipEvent_t zk_evt_get(amdzk_ctx* ctx);
 // Lane i of ctx (created on first use). While per-kernel profiling is on, a lane IS the ctx: one stream, so that the
 // event-bracketed kernel times are those of kernels running alone.
 int zk_lane(amdzk_ctx* ctx, int i, amdzk_ctx** out);
+hipError_t zk_stream_create(hipStream_t* s, bool low_priority);
 // Everything enqueued on `waiter`'s stream after this call runs after everything enqueued on `signaler`'s stream
 // before it (event record + stream wait; no host synchronisation). No-op when both are the same context.
 int zk_stream_after(amdzk_ctx* waiter, amdzk_ctx* signaler);
+// Everything enqueued on `waiter` after this call runs after the level-1 kernel of the last commitment batch launched on `signaler`.
+int zk_stream_after_l1(amdzk_ctx* waiter, amdzk_ctx* signaler);
 // Host waits for the ctx's stream and all its lanes.
 int zk_sync_all(amdzk_ctx* ctx);
 void zk_prof_drain(amdzk_ctx* ctx);

@@ -929,83 +929,91 @@ void zk_srs_free(amdzk_ctx*, amdzk_srs* s) {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// ncols MSMs of length len over srs->table[basis]; results (XYZZ) land in d_out[ncols].
-int zk_msm_dev_xyzz(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const Fr* d_scalars, size_t ncols,
-                    size_t len, size_t col_stride, G1X** d_out) {
-  if (!srs || basis < 0 || basis > 1 || !srs->table[basis]) ZK_FAIL(ctx, AMDZK_E_INVALID, "msm: basis %d not uploaded", basis);
-  if (len > srs->n) ZK_FAIL(ctx, AMDZK_E_INVALID, "msm: len %zu > 2^k = %zu", len, srs->n);
-  if (ncols == 0 || ncols > 65535) ZK_FAIL(ctx, AMDZK_E_INVALID, "msm: ncols %zu out of range", ncols);
-  const uint32_t c = srs->c, W = srs->W, nb = 1u << (c - 1);
-  const size_t ecap = align_up(len * W ? len * W : 1, 4);
-  if ((uint64_t)W * srs->n >= (1ull << 31)) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "msm: table too large for 31-bit ids");
+// One group of columns of a batch: counting sort, level-1 accumulation, folds, bucket reduction — every launch on
+// ctx->stream (the caller may have pointed it at the ctx's second MSM stream). The level-1 kernel fills the chip; what
+// precedes it (the sort) and what follows it (folds, per-bucket sums, the row/column reduction: few wavefronts,
+// latency-bound) does not. `l1_after` / `l1_done`: the level-1 launch waits for the previous group's and signals its
+// own end, so that group g's tail and group g + 2's sort run UNDER group g + 1's level-1 kernel (zk_msm_dev_xyzz).
+struct MsmGeom {
+  uint32_t c, W, nb, T1, TL, chunk, nblk;
+  size_t ecap, cap[4], G;
+  size_t o_bh, o_cnt, o_off[4], o_ent, o_list[4], o_dense, o_rows, o_cols, bytes;
+};
+static constexpr int MSM_NLEV = 3;  // level 1 + two folding levels, then the per-bucket final
 
+static MsmGeom msm_geometry(const amdzk_srs* srs, size_t ncols, size_t len, size_t ncols_for_task_size) {
+  MsmGeom g;
+  g.c = srs->c;
+  g.W = srs->W;
+  g.nb = 1u << (g.c - 1);
+  g.ecap = align_up(len * g.W ? len * g.W : 1, 4);
   // task sizes: level 1 adds T1 table points per thread, levels 2.. fold TL partial sums per thread;
   // all levels use the balanced segmented kernel. Every extra folding level costs a latency-bound launch, so two
   // folding levels; T1 = 12 for the large batches (profiles/r02j_msm_task_size.txt: T1 = 8 / 12 / 16 / 32 / 48 take
   // 5.8 / 5.7 / 6.5 / 7.1 / 7.8 ms per proof in level 1 against 2.4 / 2.1 / 1.9 / 1.6 / 1.6 in the folds — a task of 32
   // additions leaves the last of its few thousand wavefronts running alone — and 76.9 against 76.0 proofs/s for
   // 12 against 16 with ten proofs in flight). e_total is a capacity: zero digits never become entries.
-  const size_t e_total = ecap * ncols;
-  uint32_t T1 = 4;
-  if (e_total > (size_t)4 * 262144) T1 = 8;
-  if (e_total > (size_t)8 * 262144) T1 = 12;
-  if (const char* e = getenv("AMDZK_MSM_T1")) T1 = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : T1;
-  uint32_t TL = 6;  // 4 / 6 / 8 / 12 / 16 prove at the same rate (76.7-78.0 proofs/s); 6 has the shortest proof (profiles/r02j_msm_task_size.txt)
-  if (const char* e = getenv("AMDZK_MSM_TL")) TL = (uint32_t)atoi(e) > 1 ? (uint32_t)atoi(e) : TL;
-  constexpr int NLEV = 3;  // level 1 + two folding levels, then the per-bucket final
-  size_t cap[NLEV + 1];
-  cap[0] = ecap;
-  cap[1] = ecap / T1 + nb + 1;
-  for (int l = 2; l <= NLEV; l++) cap[l] = cap[l - 1] / TL + nb + 1;
+  const size_t e_total = g.ecap * ncols_for_task_size;
+  g.T1 = 4;
+  if (e_total > (size_t)4 * 262144) g.T1 = 8;
+  if (e_total > (size_t)8 * 262144) g.T1 = 12;
+  if (const char* e = getenv("AMDZK_MSM_T1")) g.T1 = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : g.T1;
+  g.TL = 6;  // 4 / 6 / 8 / 12 / 16 prove at the same rate (76.7-78.0 proofs/s); 6 has the shortest proof (profiles/r02j_msm_task_size.txt)
+  if (const char* e = getenv("AMDZK_MSM_TL")) g.TL = (uint32_t)atoi(e) > 1 ? (uint32_t)atoi(e) : g.TL;
+  g.cap[0] = g.ecap;
+  g.cap[1] = g.ecap / g.T1 + g.nb + 1;
+  for (int l = 2; l <= MSM_NLEV; l++) g.cap[l] = g.cap[l - 1] / g.TL + g.nb + 1;
   // counting-sort geometry: one workgroup per `chunk` scalars, at most 64 workgroups per column
-  uint32_t chunk = 2048;
-  while ((len + chunk - 1) / chunk > 64) chunk <<= 1;
-  const uint32_t nblk = len ? (uint32_t)((len + chunk - 1) / chunk) : 1;
-
-  // workspace layout (slot 1)
+  g.chunk = 2048;
+  while ((len + g.chunk - 1) / g.chunk > 64) g.chunk <<= 1;
+  g.nblk = len ? (uint32_t)((len + g.chunk - 1) / g.chunk) : 1;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
-  const size_t o_bh = take(ncols * (size_t)nblk * nb * 4), o_cnt = take(ncols * nb * 4);
-  size_t o_off[NLEV + 1], o_list[NLEV + 1];
-  for (int l = 0; l <= NLEV; l++) o_off[l] = take(ncols * (nb + 1) * 4);
-  const size_t o_ent = take(ncols * ecap * 4);
-  o_list[0] = 0;
-  for (int l = 1; l <= NLEV; l++) o_list[l] = take(ncols * cap[l] * sizeof(G1X29));
-  const size_t o_dense = take(ncols * nb * sizeof(G1X29));
-  const size_t G = nb >> 6;
-  const size_t o_rows = take(ncols * G * sizeof(G1X29)), o_cols = take(ncols * 64 * sizeof(G1X29));
-  const size_t o_out = take(ncols * sizeof(G1X));
-  char* ws = nullptr;
-  ZK_TRY(zk_ws_reserve(ctx, 1, o, (void**)&ws));
-  uint32_t* blk_hist = (uint32_t*)(ws + o_bh);
-  uint32_t* cnt = (uint32_t*)(ws + o_cnt);
-  uint32_t* off[NLEV + 1];
-  G1X29* list[NLEV + 1];
-  for (int l = 0; l <= NLEV; l++) off[l] = (uint32_t*)(ws + o_off[l]), list[l] = (G1X29*)(ws + o_list[l]);
-  uint32_t* entries = (uint32_t*)(ws + o_ent);
-  G1X29* dense = (G1X29*)(ws + o_dense);
-  G1X29 *rows = (G1X29*)(ws + o_rows), *cols = (G1X29*)(ws + o_cols);
-  G1X* outp = (G1X*)(ws + o_out);
+  g.o_bh = take(ncols * (size_t)g.nblk * g.nb * 4);
+  g.o_cnt = take(ncols * g.nb * 4);
+  for (int l = 0; l <= MSM_NLEV; l++) g.o_off[l] = take(ncols * (g.nb + 1) * 4);
+  g.o_ent = take(ncols * g.ecap * 4);
+  g.o_list[0] = 0;
+  for (int l = 1; l <= MSM_NLEV; l++) g.o_list[l] = take(ncols * g.cap[l] * sizeof(G1X29));
+  g.o_dense = take(ncols * g.nb * sizeof(G1X29));
+  g.G = g.nb >> 6;
+  g.o_rows = take(ncols * g.G * sizeof(G1X29));
+  g.o_cols = take(ncols * 64 * sizeof(G1X29));
+  g.bytes = o;
+  return g;
+}
+
+static int msm_group(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const MsmGeom& g, char* ws, const Fr* d_scalars, size_t ncols, size_t len,
+                     size_t col_stride, G1X* outp, hipEvent_t l1_after, hipEvent_t l1_done) {
+  const uint32_t nb = g.nb;
+  uint32_t* blk_hist = (uint32_t*)(ws + g.o_bh);
+  uint32_t* cnt = (uint32_t*)(ws + g.o_cnt);
+  uint32_t* off[MSM_NLEV + 1];
+  G1X29* list[MSM_NLEV + 1];
+  for (int l = 0; l <= MSM_NLEV; l++) off[l] = (uint32_t*)(ws + g.o_off[l]), list[l] = (G1X29*)(ws + g.o_list[l]);
+  uint32_t* entries = (uint32_t*)(ws + g.o_ent);
+  G1X29* dense = (G1X29*)(ws + g.o_dense);
+  G1X29 *rows = (G1X29*)(ws + g.o_rows), *cols = (G1X29*)(ws + g.o_cols);
 
   DigitArgs da;
   da.scalars = d_scalars;
   da.col_stride = col_stride;
   da.len = (uint32_t)len;
   da.nb = nb;
-  da.chunk = chunk;
-  da.nblk = nblk;
+  da.chunk = g.chunk;
+  da.nblk = g.nblk;
   da.blk_hist = blk_hist;
   da.off0 = off[0];
   da.entries = entries;
-  da.ecap = ecap;
+  da.ecap = g.ecap;
   da.table_n = (uint32_t)srs->n;
-  dim3 dgrid(nblk, (unsigned)ncols);
-  ZK_TRY(launch_digits<false>(ctx, c, da, dgrid));
-  ZK_LAUNCH(ctx, "msm_blk_offsets", msm_blk_offsets_kernel, dim3((nb + 255) / 256, (unsigned)ncols), dim3(256), 0, blk_hist, cnt, nb, nblk);
+  dim3 dgrid(g.nblk, (unsigned)ncols);
+  ZK_TRY(launch_digits<false>(ctx, g.c, da, dgrid));
+  ZK_LAUNCH(ctx, "msm_blk_offsets", msm_blk_offsets_kernel, dim3((nb + 255) / 256, (unsigned)ncols), dim3(256), 0, blk_hist, cnt, nb, g.nblk);
   ZK_LAUNCH(ctx, "msm_scan", msm_scan_kernel, dim3((unsigned)ncols), dim3(1024), 0, cnt, off[0], nb, 1u, 1);
-  ZK_TRY(launch_digits<true>(ctx, c, da, dgrid));
-  for (int l = 1; l <= NLEV; l++) {
-    const uint32_t T = l == 1 ? T1 : TL;
+  ZK_TRY(launch_digits<true>(ctx, g.c, da, dgrid));
+  for (int l = 1; l <= MSM_NLEV; l++) {
+    const uint32_t T = l == 1 ? g.T1 : g.TL;
     ZK_LAUNCH(ctx, "msm_scan", msm_scan_kernel, dim3((unsigned)ncols), dim3(1024), 0, off[l - 1], off[l], nb, T, 2);
     AccArgs a;
     a.off_in = off[l - 1];
@@ -1013,26 +1021,82 @@ int zk_msm_dev_xyzz(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const Fr* d
     a.nb = nb;
     a.T = T;
     a.entries = entries;
-    a.ecap = ecap;
+    a.ecap = g.ecap;
     a.table = srs->table[basis];
     a.in_list = list[l - 1];
-    a.in_cap = cap[l - 1];
+    a.in_cap = g.cap[l - 1];
     a.out_list = list[l];
-    a.out_cap = cap[l];
-    const size_t threads = (cap[l - 1] + T - 1) / T;
+    a.out_cap = g.cap[l];
+    const size_t threads = (g.cap[l - 1] + T - 1) / T;
     dim3 grid((unsigned)((threads + MSM_THREADS - 1) / MSM_THREADS), (unsigned)ncols);
-    if (l == 1)
+    if (l == 1) {
+      if (l1_after) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, l1_after, 0));
       ZK_LAUNCH(ctx, "msm_accum_l1", msm_accum_seg_kernel<true>, grid, dim3(MSM_THREADS), 0, a);
-    else
+      if (l1_done) ZK_HIP(ctx, hipEventRecord(l1_done, ctx->stream));
+    } else {
       ZK_LAUNCH(ctx, "msm_accum_fold", msm_accum_seg_kernel<false>, grid, dim3(MSM_THREADS), 0, a);
+    }
   }
-  ZK_LAUNCH(ctx, "msm_accum_final", msm_accum_final_kernel, dim3(nb / 64, (unsigned)ncols), dim3(64), 0, off[NLEV], nb, list[NLEV], cap[NLEV],
-            dense);
-  ZK_LAUNCH(ctx, "msm_rowcol", msm_rowcol_kernel, dim3((unsigned)(1 + (G + 63) / 64), (unsigned)ncols), dim3(256), 0, dense, nb, rows, cols);
-  const unsigned fold_w = (unsigned)((G + 63) / 64);  // 1, 2, 4 or 8 (c <= 16)
-  const int fold_split = fold_w <= 4;                  // at most 9 wavefronts per workgroup either way (launch bound 576)
+  ZK_LAUNCH(ctx, "msm_accum_final", msm_accum_final_kernel, dim3(nb / 64, (unsigned)ncols), dim3(64), 0, off[MSM_NLEV], nb, list[MSM_NLEV],
+            g.cap[MSM_NLEV], dense);
+  ZK_LAUNCH(ctx, "msm_rowcol", msm_rowcol_kernel, dim3((unsigned)(1 + (g.G + 63) / 64), (unsigned)ncols), dim3(256), 0, dense, nb, rows, cols);
+  const unsigned fold_w = (unsigned)((g.G + 63) / 64);  // 1, 2, 4 or 8 (c <= 16)
+  const int fold_split = fold_w <= 4;                    // at most 9 wavefronts per workgroup either way (launch bound 576)
   ZK_LAUNCH(ctx, "msm_fold", msm_fold_kernel, dim3((unsigned)ncols), dim3(64 * ((fold_split ? 2 : 1) * fold_w + 1)), 0, rows, cols, nb, outp,
             fold_split);
+  return AMDZK_OK;
+}
+
+// ncols MSMs of length len over srs->table[basis]; results (XYZZ) land in d_out[ncols].
+// With ctx->msm_pipeline (an experiment: create_proof sets it under AMDZK_MSM_PIPELINE=1) a batch of many columns is cut
+// into groups that alternate between the ctx's stream and a second stream of its own, level-1 kernels chained, so that
+// a group's latency-bound tail and sort could hide under the next group's level-1 kernel (see msm_group). It does not
+// pay on this chip — the small kernels then queue for workgroup slots behind the chip-filling one — and is off by
+// default: one group, one stream.
+int zk_msm_dev_xyzz(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const Fr* d_scalars, size_t ncols,
+                    size_t len, size_t col_stride, G1X** d_out) {
+  if (!srs || basis < 0 || basis > 1 || !srs->table[basis]) ZK_FAIL(ctx, AMDZK_E_INVALID, "msm: basis %d not uploaded", basis);
+  if (len > srs->n) ZK_FAIL(ctx, AMDZK_E_INVALID, "msm: len %zu > 2^k = %zu", len, srs->n);
+  if (ncols == 0 || ncols > 65535) ZK_FAIL(ctx, AMDZK_E_INVALID, "msm: ncols %zu out of range", ncols);
+  if ((uint64_t)srs->W * srs->n >= (1ull << 31)) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "msm: table too large for 31-bit ids");
+  // groups: at least AMDZK_MSM_GROUP_COLS columns each (default 16), at most 6
+  size_t ngroups = 1;
+  if (ctx->msm_pipeline && !ctx->prof) {
+    size_t per = 16;
+    if (const char* e = getenv("AMDZK_MSM_GROUP_COLS")) per = atoi(e) > 0 ? (size_t)atoi(e) : per;
+    ngroups = std::min<size_t>(std::max<size_t>(ncols / per, 1), 6);
+  }
+  const size_t gcols = (ncols + ngroups - 1) / ngroups;
+  ngroups = (ncols + gcols - 1) / gcols;
+  const MsmGeom g = msm_geometry(srs, gcols, len, ncols);  // task sizes as for the whole batch
+  const size_t o_out = align_up(ngroups * g.bytes, 256);
+  char* ws = nullptr;
+  ZK_TRY(zk_ws_reserve(ctx, 1, o_out + align_up(ncols * sizeof(G1X), 256), (void**)&ws));
+  G1X* outp = (G1X*)(ws + o_out);
+  if (!ctx->msm_l1_evt) ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->msm_l1_evt, hipEventDisableTiming));
+  if (ngroups == 1) {
+    ZK_TRY(msm_group(ctx, srs, basis, g, ws, d_scalars, ncols, len, col_stride, outp, nullptr, ctx->msm_l1_evt));
+    *d_out = outp;
+    return AMDZK_OK;
+  }
+  if (!ctx->msm_stream) ZK_HIP(ctx, zk_stream_create(&ctx->msm_stream, ctx->parent != nullptr));
+  for (hipEvent_t& e : ctx->msm_evt)
+    if (!e) ZK_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  hipStream_t main_stream = ctx->stream;
+  // the scalars were produced on the ctx's stream: the second stream starts after them
+  ZK_HIP(ctx, hipEventRecord(ctx->msm_evt[6], main_stream));
+  ZK_HIP(ctx, hipStreamWaitEvent(ctx->msm_stream, ctx->msm_evt[6], 0));
+  int rc = AMDZK_OK;
+  for (size_t gi = 0; gi < ngroups && rc == AMDZK_OK; gi++) {
+    const size_t first = gi * gcols, m = std::min(gcols, ncols - first);
+    ctx->stream = (gi & 1) ? ctx->msm_stream : main_stream;
+    rc = msm_group(ctx, srs, basis, g, ws + gi * g.bytes, d_scalars + first * col_stride, m, len, col_stride, outp + first,
+                   gi ? ctx->msm_evt[gi - 1] : nullptr, gi + 1 < ngroups ? ctx->msm_evt[gi] : ctx->msm_l1_evt);
+  }
+  ctx->stream = main_stream;
+  ZK_TRY(rc);
+  ZK_HIP(ctx, hipEventRecord(ctx->msm_evt[7], ctx->msm_stream));
+  ZK_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->msm_evt[7], 0));
   *d_out = outp;
   return AMDZK_OK;
 }

@@ -100,15 +100,32 @@ __device__ __forceinline__ Fr tw_lookup(const Fr* tw, uint32_t e, uint32_t log_n
 // below 2; every third round the sums are brought back below 2 with f29_reduce_weak (~30 instructions), so
 // no element exceeds 16.8 and every subtrahend stays below 9 (the range f29_sub10 covers). Elements are
 // packed to canonical 32-byte values only when they leave the tile.
+// Element e of the tile sits at slot e + (e >> 5): one empty slot per 32 elements. The radix-4 blocks read and write
+// runs of 2^(a-1) * C consecutive elements that are 4 runs apart; in the last blocks a run is 4-16 elements, and without
+// the skew the runs of a half-wavefront would all start on the same banks (8-way conflicts at run length 4).
+__device__ __forceinline__ uint32_t tile_slot(uint32_t e) { return e + (e >> 5); }
 __device__ __forceinline__ Fr29 lds_ld(const uint32_t* L, uint32_t e) {
   Fr29 r;
+  const uint32_t s = tile_slot(e) * 9;
 #pragma unroll
-  for (int i = 0; i < 9; i++) r.l[i] = L[e * 9 + i];
+  for (int i = 0; i < 9; i++) r.l[i] = L[s + i];
   return r;
 }
 __device__ __forceinline__ void lds_st(uint32_t* L, uint32_t e, const Fr29& v) {
+  const uint32_t s = tile_slot(e) * 9;
 #pragma unroll
-  for (int i = 0; i < 9; i++) L[e * 9 + i] = v.l[i];
+  for (int i = 0; i < 9; i++) L[s + i] = v.l[i];
+}
+// the staged sub-transform twiddles: plain indexing
+__device__ __forceinline__ Fr29 tw_ld(const uint32_t* T, uint32_t i) {
+  Fr29 r;
+#pragma unroll
+  for (int k = 0; k < 9; k++) r.l[k] = T[i * 9 + k];
+  return r;
+}
+__device__ __forceinline__ void tw_st(uint32_t* T, uint32_t i, const Fr29& v) {
+#pragma unroll
+  for (int k = 0; k < 9; k++) T[i * 9 + k] = v.l[k];
 }
 __device__ __forceinline__ Fr pack_out(const Fr29& v_below_2p) { return f29_pack_canonical<FrP>(v_below_2p); }
 
@@ -120,7 +137,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
   const uint32_t C = 1u << a.log_c;
   const uint32_t rows = 1u << a.s;
   const uint32_t tile = rows << a.log_c;
-  uint32_t* TW = L + (size_t)tile * 9;  // rows/2 sub-transform twiddles omega_{n_p}^i (radix 2^261), as limbs
+  uint32_t* TW = L + (size_t)(tile + (tile >> 5) + 1) * 9;  // rows/2 sub-transform twiddles omega_{n_p}^i (radix 2^261), as limbs
   const uint32_t tile_id = blockIdx.x;
   const Fr* in = a.in + (size_t)blockIdx.y * a.in_col_stride + (size_t)blockIdx.z * a.in_z_stride;
   Fr* out = a.out + (size_t)blockIdx.y * a.out_col_stride + (size_t)blockIdx.z * a.out_z_stride;
@@ -129,7 +146,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
   const uint32_t log_n = a.log_n;
 
   // ---- stage the sub-transform twiddles: omega_{n_p}^i = omega^(i * n/n_p)
-  for (uint32_t i = tid; i < (rows >> 1); i += NTT_THREADS) lds_st(TW, i, fr29_unpack(ld_fr(a.tw + ((size_t)i << (log_n - a.s)))));
+  for (uint32_t i = tid; i < (rows >> 1); i += NTT_THREADS) tw_st(TW, i, fr29_unpack(ld_fr(a.tw + ((size_t)i << (log_n - a.s)))));
 
   // ---- load the tile (whole elements; consecutive lanes read consecutive elements of a contiguous run)
   size_t in_base, row_stride;
@@ -188,23 +205,57 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
     __syncthreads();
   }
 
-  // ---- radix-2 DIF rounds over the row dimension; result row r holds output index brev(r)
-  uint32_t round = 0;
-  for (int st = (int)a.s - 1; st >= 0; --st, ++round) {
+  // ---- DIF rounds over the row dimension, two at a time: a thread takes the four elements x0 + j * 2^(a-1), j < 4, of
+  // rounds a and a - 1 (half-lengths 2^a and 2^(a-1)) through both rounds in registers — one LDS round trip and one
+  // barrier per TWO rounds, three twiddle loads for four butterflies. Result row r holds output index brev(r).
+  // An odd number of rounds starts with a single round. The last block (a = 1) multiplies by ONE constant only: its
+  // round-1 twiddles are omega^0 (skipped) and omega_4, round 0 has none — 1 product where the round-by-round code
+  // spent 4. Bounds in units of p: every element enters a block below 4 (2 at the start); sums of the first round are
+  // below 8 (a valid subtrahend of f29_sub10*), twiddle products below 2, so the block leaves below 1.0002 (x0: the
+  // sum of sums, weakly reduced), 2, 4, 2 — and the last block, which has differences without a product behind them,
+  // below 18, 16, 24: all inside the range of the product / weak reduction every element leaves the tile through.
+  int st = (int)a.s - 1;
+  if (a.s & 1) {  // single round, half-length 2^(s-1): butterfly (x, x + h), twiddle omega_{n_p}^x
     const uint32_t h = 1u << st;
-    const bool reduce_sums = (round % 3) == 2;
     for (uint32_t b = tid; b < (tile >> 1); b += NTT_THREADS) {
-      uint32_t c = b & (C - 1), m = b >> a.log_c;
-      uint32_t i = m & (h - 1), blk = m >> st;
-      uint32_t x0 = (blk << (st + 1)) + i;
-      uint32_t e0 = (x0 << a.log_c) + c, e1 = ((x0 + h) << a.log_c) + c;
-      Fr29 u = lds_ld(L, e0), v = lds_ld(L, e1);
-      Fr29 sum = f29_add(u, v);
-      if (reduce_sums) sum = f29_reduce_weak(sum);
-      lds_st(L, e0, sum);
-      // below bound(u) + 10; where a twiddle product follows, the difference enters it without its carry pass
-      const Fr29 d = st > 0 ? f29_mul(f29_sub10_lazy(u, v), lds_ld(TW, i << (a.s - 1 - st))) : f29_sub10(u, v);
-      lds_st(L, e1, d);
+      const uint32_t c = b & (C - 1), x0 = b >> a.log_c;
+      const uint32_t e0 = (x0 << a.log_c) + c, e1 = ((x0 + h) << a.log_c) + c;
+      const Fr29 u = lds_ld(L, e0), v = lds_ld(L, e1);
+      lds_st(L, e0, f29_add(u, v));
+      lds_st(L, e1, st > 0 ? f29_mul(f29_sub10_lazy(u, v), tw_ld(TW, x0)) : f29_sub10(u, v));
+    }
+    __syncthreads();
+    st--;
+  }
+  for (; st >= 1; st -= 2) {  // rounds st and st - 1
+    const uint32_t hq = 1u << (st - 1);  // distance between the four elements of a group
+    const uint32_t estep = hq << a.log_c;
+    const bool last_block = st == 1;
+    for (uint32_t q = tid; q < (tile >> 2); q += NTT_THREADS) {
+      const uint32_t c = q & (C - 1), gq = q >> a.log_c;
+      const uint32_t lo = gq & (hq - 1), hi = gq >> (st - 1);
+      const uint32_t e0 = ((((hi << 2) << (st - 1)) | lo) << a.log_c) + c, e1 = e0 + estep, e2 = e1 + estep, e3 = e2 + estep;
+      const Fr29 u0 = lds_ld(L, e0), u1 = lds_ld(L, e1), u2 = lds_ld(L, e2), u3 = lds_ld(L, e3);
+      const Fr29 s0 = f29_add(u0, u2), s1 = f29_add(u1, u3);
+      Fr29 y1, y2, y3;
+      if (last_block) {
+        const Fr29 d0 = f29_sub10(u0, u2);                                                       // omega^0
+        const Fr29 d1 = f29_mul(f29_sub10_lazy(u1, u3), tw_ld(TW, 1u << (a.s - 2)));             // omega_4
+        y1 = f29_sub10(s0, s1);
+        y2 = f29_add(d0, d1);
+        y3 = f29_sub10(d0, d1);
+      } else {
+        const Fr29 d0 = f29_mul(f29_sub10_lazy(u0, u2), tw_ld(TW, lo << (a.s - 1 - st)));
+        const Fr29 d1 = f29_mul(f29_sub10_lazy(u1, u3), tw_ld(TW, (lo + hq) << (a.s - 1 - st)));
+        const Fr29 w = tw_ld(TW, lo << (a.s - st));
+        y1 = f29_mul(f29_sub10_lazy(s0, s1), w);
+        y2 = f29_add(d0, d1);
+        y3 = f29_mul(f29_sub10_lazy(d0, d1), w);
+      }
+      lds_st(L, e0, f29_reduce_weak(f29_add(s0, s1)));
+      lds_st(L, e1, y1);
+      lds_st(L, e2, y2);
+      lds_st(L, e3, y3);
     }
     __syncthreads();
   }
@@ -402,7 +453,8 @@ int zk_ntt_ex(amdzk_ctx* ctx, const Fr* d_in, size_t in_stride, Fr* d_out, size_
     }
     const uint32_t tile_elems_log = a.s + a.log_c;
     dim3 grid((uint32_t)(n >> tile_elems_log), (uint32_t)ncols, nz), block(NTT_THREADS);
-    size_t shmem = (((size_t)1 << tile_elems_log) + ((size_t)1 << a.s) / 2 + 1) * 9 * sizeof(uint32_t);  // limbs, see ntt_step_kernel
+    const size_t tile_elems = (size_t)1 << tile_elems_log;
+    size_t shmem = (tile_elems + (tile_elems >> 5) + 1 + ((size_t)1 << a.s) / 2 + 1) * 9 * sizeof(uint32_t);  // limbs + skew slots, see ntt_step_kernel
     if (last) {
       if (shmem > 65536) ZK_HIP(ctx, hipFuncSetAttribute((const void*)ntt_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
       ZK_LAUNCH(ctx, "ntt_step_last", ntt_step_kernel<true>, grid, block, shmem, a);

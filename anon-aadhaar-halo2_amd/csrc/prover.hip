@@ -1431,7 +1431,19 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
                              size_t* proof_len) {
   ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
+  // AMDZK_MSM_PIPELINE=1 (experiment, off by default): lanes mode also cuts every commitment batch into column groups on
+  // two streams with chained level-1 kernels (msm.hip zk_msm_dev_xyzz). Measured slower on both counts — 22.7-25.8 ms
+  // against 21.5 for one proof, 66-74 against 74 proofs/s — because a group's small kernels wait for workgroup slots
+  // behind the other group's level-1 kernel (profiles/r03b_stream_priorities_and_gating.txt). The caller's ctx gets
+  // its own setting back.
+  const bool keep_pipeline = ctx->msm_pipeline;
+  if (pk && pk->use_lanes && getenv("AMDZK_MSM_PIPELINE") && atoi(getenv("AMDZK_MSM_PIPELINE")) != 0) {
+    ctx->msm_pipeline = true;
+    for (amdzk_ctx* l : ctx->lanes)
+      if (l) l->msm_pipeline = true;
+  }
   const int r = create_proof_body(ctx, pk, instances, instance_lens, d_advice, advice_stride, rng, transcript_kind, proof_out, proof_cap, proof_len);
+  ctx->msm_pipeline = keep_pipeline;
   if (r != AMDZK_OK) {  // a failed proof may have left work on the lanes: the key's workspace must be quiet before it is used again
     const std::string keep = ctx->err;
     (void)zk_sync_all(ctx);
@@ -1475,6 +1487,7 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
   if (pk->use_lanes) {
     ZK_TRY(zk_lane(ctx, 0, &B));
     ZK_TRY(zk_lane(ctx, 1, &C));
+    B->msm_pipeline = C->msm_pipeline = ctx->msm_pipeline;
   }
   const bool serial = B == M;
   auto lane_id = [&](amdzk_ctx* l) { return l == M ? 0 : l == B ? 1 : 2; };
@@ -1525,9 +1538,14 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     return AMDZK_OK;
   };
   // columns [first, first + count) of the arena, blinded on lane `after`: coefficients (PQ) and quotient-domain values (PC) on B
-  auto transforms_on_B = [&](amdzk_ctx* after, size_t first, size_t count) -> int {
+  // after_l1: the columns' commitment batch has already been launched on `after`; the transforms start behind its
+  // level-1 kernel (both fill the chip: side by side they only stretch each other) and run beside its tail and beside
+  // the next phase's latency-bound kernels instead
+  static const bool gate_l1 = !(getenv("AMDZK_NTT_AFTER_L1") && atoi(getenv("AMDZK_NTT_AFTER_L1")) == 0);
+  auto transforms_on_B = [&](amdzk_ctx* after, size_t first, size_t count, bool after_l1 = false) -> int {
     if (!count) return AMDZK_OK;
-    ZK_TRY(zk_stream_after(B, after));
+    if (after_l1 && gate_l1) ZK_TRY(zk_stream_after_l1(B, after));
+    else ZK_TRY(zk_stream_after(B, after));
     LN_TRY(B, zk_lagrange_to_coeff(B, pk->dom, pk->P + first * n, n, pk->PQ + first * n, n, count));
     LN_TRY(B, zk_coeff_to_cosets_r261(B, pk->dom, pk->PQ + first * n, n, pk->PC + first * pk->ext, pk->ext, count));
     return AMDZK_OK;
@@ -1577,11 +1595,13 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     for (uint32_t c = 0; c < A; c++) (void)rng.fr();
     ZK_TRY(blind_rows(M, pk->adv(), A, usable, bf + 1, tail));
   }
-  ZK_TRY(transforms_on_B(M, 0, (size_t)A + I));
-  if (A) {
-    std::vector<G1Affine> cm;
-    ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G_LAGRANGE, pk->adv(), A, cm));
-    ZK_TRY(write_points(cm, "advice"));
+  {
+    Commit cm;
+    if (A && !serial && gate_l1) ZK_TRY(commit_begin(M, AMDZK_BASIS_G_LAGRANGE, pk->adv(), A, cm));
+    ZK_TRY(transforms_on_B(M, 0, (size_t)A + I, cm.begun));
+    if (A && !cm.begun) ZK_TRY(commit_begin(M, AMDZK_BASIS_G_LAGRANGE, pk->adv(), A, cm));
+    ZK_TRY(commit_end(cm));
+    ZK_TRY(write_points(cm.pts, "advice"));
   }
   ZK_TRY(commit_end(cm_rnd));  // long done; lane C's MSM workspace is free for the lookup products' commitment
   tick("advice");
@@ -1607,9 +1627,12 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     ZK_TRY(blind_rows(M, pk->la(), L, usable, bf + 1, ta));
     ZK_TRY(upload_small(ts, ta.size()));
     ZK_TRY(zk_scatter_rows(ctx, pk->ls(), n, usable, pk->small + ta.size(), bf + 1, L));
-    ZK_TRY(transforms_on_B(M, (size_t)A + I, 2 * (size_t)L));
-    std::vector<G1Affine> cm;
-    ZK_TRY(commit_cols(ctx, pk, AMDZK_BASIS_G_LAGRANGE, pk->la(), 2 * L, cm));
+    Commit cmc;
+    if (!serial && gate_l1) ZK_TRY(commit_begin(M, AMDZK_BASIS_G_LAGRANGE, pk->la(), 2 * L, cmc));
+    ZK_TRY(transforms_on_B(M, (size_t)A + I, 2 * (size_t)L, cmc.begun));
+    if (!cmc.begun) ZK_TRY(commit_begin(M, AMDZK_BASIS_G_LAGRANGE, pk->la(), 2 * L, cmc));
+    ZK_TRY(commit_end(cmc));
+    const std::vector<G1Affine>& cm = cmc.pts;
     for (uint32_t l = 0; l < L; l++) {
       std::vector<G1Affine> two = {cm[l], cm[L + l]};
       ZK_TRY(write_points(two, "lookup_permuted"));
@@ -1663,13 +1686,15 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     ZK_TRY(zk_running_product(ctx, pk->zp(), ns, n, n, true, usable, pk->scan_tmp));
     tick("  perm: running product");
     ZK_TRY(blind_rows(M, pk->zp(), ns, n - bf, bf, tail_p));
-    ZK_TRY(transforms_on_B(M, (size_t)A + I + 2 * L, ns));
+    if (serial || !gate_l1) ZK_TRY(transforms_on_B(M, (size_t)A + I + 2 * L, ns));
     ZK_TRY(commit_begin(M, AMDZK_BASIS_G_LAGRANGE, pk->zp(), ns, cm_zp));
   }
   if (L) {
-    ZK_TRY(transforms_on_B(C, (size_t)A + I + 2 * L + ns, L));
+    if (serial || !gate_l1) ZK_TRY(transforms_on_B(C, (size_t)A + I + 2 * L + ns, L));
     ZK_TRY(commit_begin(C, AMDZK_BASIS_G_LAGRANGE, pk->zl(), L, cm_zl));
+    if (!serial && gate_l1) ZK_TRY(transforms_on_B(C, (size_t)A + I + 2 * L + ns, L, true));
   }
+  if (ns && !serial && gate_l1) ZK_TRY(transforms_on_B(M, (size_t)A + I + 2 * L, ns, true));
   ZK_TRY(commit_end(cm_zp));
   ZK_TRY(write_points(cm_zp.pts, "perm_z"));
   tick("perm_products");

@@ -159,7 +159,14 @@ class GpuProver:
         self.params = pkg.kzg.ParamsKZG.setup(ctx, self.K, mont_limbs(self.s_int), want_host_copy=want_host_srs)
         fixed_host = self.to_mont_dev(c.fixed).cpu().numpy().view(np.uint64)
         tr = mont_limbs(self.tr_int)
-        self.pks = [self.plonk.ProvingKey(cx, self.params, self.desc, fixed_host, c.assembly.mapping, tr) for cx in self.ctxs]
+        # Key modes (include/amdzk.h AMDZK_KEYGEN_*): with several proofs in flight per GPU every proof stays on ONE stream
+        # (serial keys: the proofs already fill the chip between them; spreading each over three streams as well costs
+        # 1-2 % of the rate, profiles/r03b_*); the single-proof latency is measured with a default (lanes) key.
+        self.serial_keys = P >= 4 and os.environ.get("AMDZK_BENCH_LANES_KEYS") != "1"
+        flags = self.plonk.KEYGEN_SERIAL if self.serial_keys else 0
+        self.pks = [self.plonk.ProvingKey(cx, self.params, self.desc, fixed_host, c.assembly.mapping, tr, flags=flags) for cx in self.ctxs]
+        self.fixed_host, self.tr = fixed_host, tr
+        self._lat_keys = {}
         # resident witnesses (Montgomery form, device) + the same in pinned host memory for the PCIe-inclusive pass
         self.witness_ints = []
         self.adv, self.inst = [], []
@@ -184,31 +191,26 @@ class GpuProver:
     def prove(self, w, wi, seed):
         return self.plonk.create_proof(self.ctxs[w], self.pks[w], self.inst[wi], self.d_adv[wi], seed=seed)
 
-    def latency(self, seed, reps=3, pk=None):
-        """One proof alone on the GPU, `reps` times: (median ms, the last proof)."""
-        pk = pk or self.pks[0]
-        ms = []
-        for r in range(reps):
-            self.ctx.sync()
-            t = time.perf_counter()
-            proof = self.plonk.create_proof(self.ctx, pk, self.inst[0], self.d_adv[0], seed=seed)
-            ms.append((time.perf_counter() - t) * 1e3)
-        return sorted(ms)[len(ms) // 2], proof
-
-    def latency_serial_key(self, reference_proof, seed):
-        """The same with a key made with AMDZK_KEYGEN_SERIAL: one proof's kernels on ONE stream, strictly one after
-        another (what every key did in rounds 1-2). Same bytes, or the run fails."""
-        fixed_host = self.to_mont_dev(self.circuit.fixed).cpu().numpy().view(self.np.uint64)
-        pk = self.plonk.ProvingKey(self.ctx, self.params, self.desc, fixed_host, self.circuit.assembly.mapping, mont_limbs(self.tr_int),
-                                   flags=self.plonk.KEYGEN_SERIAL)
+    def latency(self, seed, serial, reps=3):
+        """One proof alone on the GPU with a key of the given mode — default: the proof's independent work on three streams
+        (lanes); serial: one stream, as in rounds 1-2 — `reps` times after one untimed proof: (median ms, the last proof)."""
+        want_flags = self.plonk.KEYGEN_SERIAL if serial else 0
+        if bool(serial) == bool(self.serial_keys):
+            pk, own = self.pks[0], False
+        else:
+            pk, own = self.plonk.ProvingKey(self.ctx, self.params, self.desc, self.fixed_host, self.circuit.assembly.mapping, self.tr, flags=want_flags), True
         try:
             self.plonk.create_proof(self.ctx, pk, self.inst[0], self.d_adv[0], seed=seed + 1)  # workspaces in steady state
-            ms, proof = self.latency(seed, pk=pk)
+            ms = []
+            for r in range(reps):
+                self.ctx.sync()
+                t = time.perf_counter()
+                proof = self.plonk.create_proof(self.ctx, pk, self.inst[0], self.d_adv[0], seed=seed)
+                ms.append((time.perf_counter() - t) * 1e3)
         finally:
-            pk.free()
-        if proof != reference_proof:
-            raise SystemExit("bench.py: the proof of the serial-mode key differs from the default (lanes) key's")
-        return ms
+            if own:
+                pk.free()
+        return sorted(ms)[len(ms) // 2], proof
 
     def sync(self):
         for cx in self.ctxs:
@@ -451,8 +453,11 @@ def run_rank(args):
         # single-proof latency: one proof alone on the GPU, no per-kernel events (median of 3); then the same with a
         # serial-mode key (one stream), whose proof must be the same bytes
         prover.sync()
-        lat_ms, ref = prover.latency(777001)
-        lat_serial_ms = None if args.no_serial_latency else prover.latency_serial_key(ref, 777001)
+        lat_ms, ref = prover.latency(777001, serial=False)
+        if not args.no_serial_latency:
+            lat_serial_ms, other = prover.latency(777001, serial=True)
+            if other != ref:
+                raise SystemExit("bench.py: the proof of the serial-mode key differs from the default (lanes) key's")
         if not args.no_k22:
             k22 = k22_stress(prover, want_cpu=not args.no_cpu_baseline)
         if not args.no_cpu_baseline:
@@ -496,6 +501,9 @@ def run_rank(args):
                                                   % (desc["num_advice"] * prover.n * 32 / 2 ** 20) if stream_rate else None,
                            "gather": ("all_gather of %d proofs, every rank's own proofs found in place" % (world * steps)) if gathered_ok else None,
                            "parallelism": "independent proofs sharded across GPUs, %d in flight per GPU" % P,
+                           "key_mode": ("serial keys for the timed steps (one stream per proof; %d proofs in flight fill the chip), "
+                                        "default lanes key for single_proof_latency_ms" % P) if getattr(prover, "serial_keys", False)
+                           else "default (lanes) keys",
                            "setup_s_excluded": round(prover.setup_s, 1)},
                 "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)

@@ -39,12 +39,16 @@ template <class PF, class OF> static int field_checks(const char* name) {
     OF a = rnd<OF>();
     PF pa = conv<PF>(a);
     CHECK(same(bn254::inv(pa), a.invert()));
+    CHECK(same(bn254::inv_gcd(pa), a.invert()));
     uint64_t raw[4]; a.to_raw(raw);
     PF fm = bn254::from_mont(pa);
     CHECK(memcmp(fm.l, raw, 32) == 0);
     CHECK(same(bn254::to_mont(fm), a));
   }
   CHECK(same(bn254::inv(PF::zero()), OF::zero()));
+  CHECK(same(bn254::inv_gcd(PF::zero()), OF::zero()));
+  CHECK(same(bn254::inv_gcd(PF::one()), OF::one()));
+  CHECK(same(bn254::inv_gcd(conv<PF>(OF::zero() - OF::one())), OF::zero() - OF::one()));  // (p-1)^-1 = p-1
   CHECK(same(PF::one(), OF::one()));
   printf("%s ok\n", name);
   return 0;

@@ -43,6 +43,27 @@ def test_batch_mode_shards_config4_over_ranks():
     assert ln["n_gpus"] == 2 and ln["steps"] == 4 and ln["config"]["batch"] == 8 and ln["config"]["proofs_total"] == 8
 
 
+def test_config4_verbatim_eight_ranks_batch_64():
+    """BASELINE config 4's rank and batch count (8 ranks x 8 proofs, gathered on every rank), on CPU with the stub: the
+    launcher, the rendezvous of 8 processes on 127.0.0.1, the barriers around 5 timed regions and the 64-proof gather."""
+    r = run_bench(["--gpus", "8", "--batch", "64", "--warmup", "1", "--concurrency", "2"], {"AMDZK_BENCH_STUB": "1"}, timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = json_lines(r.stdout)
+    assert len(lines) == 1
+    ln = lines[0]
+    assert ln["n_gpus"] == 8 and ln["steps"] == 8 and ln["config"]["batch"] == 64 and ln["config"]["proofs_total"] == 64
+    assert "all_gather of 64 proofs" in ln["config"]["gather"]
+    assert len(ln["config"]["value_samples"]) == 5 and sorted(ln["config"]["value_samples"])[2] == ln["value"]
+    assert ln["config"]["host_threads"] == 3 and ln["config"]["host_cpu_s_per_proof"] >= 0
+
+
+def test_host_cores_confines_the_rank():
+    r = run_bench(["--steps", "3", "--warmup", "0", "--host-cores", "2", "--regions", "1"], {"AMDZK_BENCH_STUB": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    ln = json_lines(r.stdout)[0]
+    assert ln["config"]["host_cores_allowed"] == min(2, len(os.sched_getaffinity(0)))
+
+
 def test_batch_must_divide():
     r = run_bench(["--gpus", "2", "--batch", "7"], {"AMDZK_BENCH_STUB": "1"})
     assert r.returncode != 0 and "multiple" in r.stderr

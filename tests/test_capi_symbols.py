@@ -72,3 +72,23 @@ def test_library_load_sets_hw_queue_default_without_overriding():
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, out.stderr
         assert out.stdout.strip() == want, (preset, out.stdout, out.stderr)
+
+
+def test_integration_md_ffi_block_is_the_headers():
+    """INTEGRATION.md's Rust `extern "C"` block is generated from include/amdzk.h (tools/gen_rust_ffi.py): every function
+    the header declares appears in it, with the generator's signature, and nothing else does (the
+    hand-written block had drifted — 28 of 70 functions missing)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_rust_ffi as g
+
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    i, j = doc.index(g.BEGIN), doc.index(g.END)
+    block = doc[i + len(g.BEGIN):j].strip()
+    assert block == "```rust\n" + g.block() + "\n```", "run `python tools/gen_rust_ffi.py --update`"
+    names = re.findall(r"pub fn (amdzk_\w+)\(", block)
+    assert sorted(names) == declared_functions() and len(names) == len(set(names))
+    # spot checks of the C -> Rust type mapping
+    assert "pub fn amdzk_ntt_fr_batch(ctx: *mut Ctx, cols: *const *mut u64, ncols: usize, log_n: u32, omega: *const u64, flags: u32) -> c_int;" in block
+    assert "pub fn amdzk_last_error(ctx: *const Ctx) -> *const c_char;" in block
+    assert "pub fn amdzk_destroy(ctx: *mut Ctx);" in block

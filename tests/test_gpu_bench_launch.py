@@ -19,7 +19,7 @@ def test_two_ranks_on_one_gpu_batch_mode():
         env.pop(k, None)
     env.update({"AMDZK_BENCH_FORCE_DEVICE": "0", "AMDZK_BENCH_BACKEND": "gloo"})
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "8", "--shape", "k15", "--warmup", "1",
-                        "--concurrency", "2", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+                        "--concurrency", "2", "--no-cpu-baseline", "--no-k22", "--regions", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -29,3 +29,4 @@ def test_two_ranks_on_one_gpu_batch_mode():
     assert "all_gather of 8 proofs" in ln["config"]["gather"]
     assert ln["config"]["pcie_inclusive_proofs_per_s"] > 0  # the streamed pass ran and its proofs equalled the resident ones
     assert ln["roofline"]["kernel"].startswith("msm") and ln["value"] > 1.0
+    assert len(ln["config"]["value_samples"]) == 2 and ln["config"]["host_cpu_s_per_proof"] > 0 and ln["config"]["host_threads"] == 3
