@@ -34,7 +34,7 @@ int zk_ws_reserve(amdzk_ctx* ctx, int slot, size_t bytes, void** out) {
   amdzk_ctx::Ws& w = ctx->ws[slot];
   if (w.cap < bytes) {
     if (w.p) {
-      ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
       ZK_HIP(ctx, hipFree(w.p));
       w.p = nullptr;
       w.cap = 0;
@@ -78,7 +78,7 @@ hipEvent_t zk_evt_get(amdzk_ctx* ctx) {
 
 void zk_prof_drain(amdzk_ctx* ctx) {
   if (ctx->pending.empty()) return;
-  hipStreamSynchronize(ctx->stream);
+  zk_host_wait(ctx, ctx->stream);
   for (auto& p : ctx->pending) {
     float ms = 0.f;
     hipEventElapsedTime(&ms, p.a, p.b);
@@ -109,6 +109,9 @@ int zk_ptr_on_device(amdzk_ctx* ctx, const void* p, const char* what) {
 // latency-bound kernels would not queue behind a chip-filling transform — made EVERYTHING slower on this runtime:
 // 56 ms instead of 21 for one proof, 57 instead of 72 proofs/s with ten in flight, 39 ms even for a serial-mode key;
 // profiles/r03b_stream_priorities_and_gating.txt.)
+// Also measured and rejected: keeping the lanes' streams off every 2nd / 4th / 8th compute unit (a CU mask,
+// hipExtStreamCreateWithCUMask) so that the caller's stream always finds free compute units: 19.8-19.95 ms per proof
+// against 19.35 without (profiles/r03e_host_wait_and_cu_mask.txt).
 hipError_t zk_stream_create(hipStream_t* s, bool /*lane*/) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
 
 int zk_lane(amdzk_ctx* ctx, int i, amdzk_ctx** out) {
@@ -150,18 +153,18 @@ int zk_stream_after_l1(amdzk_ctx* waiter, amdzk_ctx* signaler) {
 
 int zk_sync_all(amdzk_ctx* ctx) {
   amdzk_ctx* root = ctx->parent ? ctx->parent : ctx;
-  ZK_HIP(ctx, hipStreamSynchronize(root->stream));
-  if (root->msm_stream) ZK_HIP(ctx, hipStreamSynchronize(root->msm_stream));
+  ZK_HIP(ctx, zk_host_wait(root, root->stream));
+  if (root->msm_stream) ZK_HIP(ctx, zk_host_wait(root, root->msm_stream));
   for (amdzk_ctx* l : root->lanes)
     if (l) {
-      ZK_HIP(ctx, hipStreamSynchronize(l->stream));
-      if (l->msm_stream) ZK_HIP(ctx, hipStreamSynchronize(l->msm_stream));
+      ZK_HIP(ctx, zk_host_wait(l, l->stream));
+      if (l->msm_stream) ZK_HIP(ctx, zk_host_wait(l, l->msm_stream));
     }
   return AMDZK_OK;
 }
 
 static void ctx_release(amdzk_ctx* ctx) {
-  hipStreamSynchronize(ctx->stream);
+  zk_host_wait(ctx, ctx->stream);
   zk_prof_drain(ctx);
   for (auto& kv : ctx->twiddles) hipFree(kv.second);
   for (auto& w : ctx->ws)
@@ -173,6 +176,7 @@ static void ctx_release(amdzk_ctx* ctx) {
   for (auto e : ctx->msm_evt)
     if (e) hipEventDestroy(e);
   if (ctx->msm_l1_evt) hipEventDestroy(ctx->msm_l1_evt);
+  if (ctx->wait_evt) hipEventDestroy(ctx->wait_evt);
   if (ctx->msm_stream) {
     hipStreamSynchronize(ctx->msm_stream);
     hipStreamDestroy(ctx->msm_stream);
@@ -241,6 +245,7 @@ int amdzk_init(int device_id, amdzk_ctx** out) {
     return AMDZK_E_HIP;
   }
   c->stream = c->own_stream;
+  if (const char* e = getenv("AMDZK_HOST_WAIT")) c->host_wait_block = strcmp(e, "block") == 0;
   hipEventCreate(&c->t0);
   hipEventCreate(&c->t1);
   note_context_created();
@@ -265,8 +270,15 @@ const char* amdzk_last_error(const amdzk_ctx* ctx) { return ctx ? ctx->err.c_str
 int amdzk_set_stream(amdzk_ctx* ctx, void* hip_stream) {
   ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return AMDZK_OK;
+}
+
+int amdzk_set_host_wait(amdzk_ctx* ctx, int mode) {
+  if (!ctx) return AMDZK_E_INVALID;
+  if (mode != AMDZK_WAIT_SPIN && mode != AMDZK_WAIT_BLOCK) ZK_FAIL(ctx, AMDZK_E_INVALID, "set_host_wait: unknown mode %d", mode);
+  ctx->host_wait_block = mode == AMDZK_WAIT_BLOCK;
   return AMDZK_OK;
 }
 
@@ -287,7 +299,7 @@ int amdzk_dev_free(amdzk_ctx* ctx, void* dptr) {
   ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
   if (!dptr) return AMDZK_OK;
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   ZK_HIP(ctx, hipFree(dptr));
   return AMDZK_OK;
 }
@@ -295,14 +307,14 @@ int amdzk_dev_upload(amdzk_ctx* ctx, void* dptr, const void* host, size_t bytes)
   ZK_ENTER(ctx);
   if (!ctx || (!dptr && bytes) || (!host && bytes)) return AMDZK_E_INVALID;
   ZK_HIP(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   return AMDZK_OK;
 }
 int amdzk_dev_download(amdzk_ctx* ctx, void* host, const void* dptr, size_t bytes) {
   ZK_ENTER(ctx);
   if (!ctx || (!dptr && bytes) || (!host && bytes)) return AMDZK_E_INVALID;
   ZK_HIP(ctx, hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   return AMDZK_OK;
 }
 // ---- streaming inputs: pinned host memory + uploads on a copy stream of the ctx's own
@@ -403,7 +415,7 @@ int amdzk_srs_read(amdzk_ctx* ctx, const uint8_t* data, size_t len, amdzk_srs** 
 }
 void amdzk_srs_free(amdzk_ctx* ctx, amdzk_srs* srs) {
   ZK_ENTER(ctx);
-  if (ctx) hipStreamSynchronize(ctx->stream);
+  if (ctx) zk_host_wait(ctx, ctx->stream);
   zk_srs_free(ctx, srs);
 }
 
@@ -458,7 +470,7 @@ int amdzk_ntt_fr(amdzk_ctx* ctx, uint64_t* a, uint32_t log_n, const uint64_t ome
   ZK_HIP(ctx, hipMemcpyAsync(d, a, bytes, hipMemcpyHostToDevice, ctx->stream));
   ZK_TRY(zk_ntt_dev(ctx, d, log_n, omega, flags, 1, (size_t)1 << log_n));
   ZK_HIP(ctx, hipMemcpyAsync(a, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   return AMDZK_OK;
 }
 
@@ -501,7 +513,7 @@ int amdzk_ntt_fr_batch(amdzk_ctx* ctx, uint64_t* const* cols, size_t ncols, uint
   }
   ZK_TRY(zk_ntt_dev(ctx, d, log_n, omega, flags, ncols, n));
   for (size_t c = 0; c < ncols; c++) ZK_HIP(ctx, hipMemcpyAsync(cols[c], d + c * n, n * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   return AMDZK_OK;
 }
 

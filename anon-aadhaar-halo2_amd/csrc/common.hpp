@@ -5,8 +5,10 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <chrono>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/amdzk.h"
@@ -62,6 +64,12 @@ struct amdzk_ctx {
   // pinned host staging for small results
   void* h_pinned = nullptr;
   size_t h_pinned_cap = 0;
+
+  // How the host waits for the device (zk_host_wait): spinning in hipStreamSynchronize — lowest latency, one busy core
+  // per waiting thread — or sleeping on a blocking-sync event — the thread leaves its core to the other proofs' drivers.
+  // amdzk_set_host_wait / AMDZK_HOST_WAIT=block; lanes follow their parent.
+  bool host_wait_block = false;
+  hipEvent_t wait_evt = nullptr;
 
   // Lanes: auxiliary contexts on the same device (own stream, workspaces, staging) for work of ONE call that is
   // independent of what the call's main stream is doing — create_proof puts the coset transforms of a phase's columns,
@@ -129,6 +137,31 @@ struct ZkDeviceGuard {
     int _r = (expr);            \
     if (_r != AMDZK_OK) return _r; \
   } while (0)
+
+// Host waits until everything enqueued on `s` (a stream of ctx) has completed. Spin mode: hipStreamSynchronize (the
+// runtime busy-waits: lowest latency, one core per waiting thread). Block mode: an event recorded behind the work is
+// POLLED — a few microseconds of yielding, then 50-microsecond sleeps — so that a waiting thread leaves its core to
+// the threads that have kernels to launch. (The runtime's own blocking waits are not usable here: events created with
+// hipEventBlockingSync still spin in hipEventSynchronize on this ROCm, and the device-wide
+// hipDeviceScheduleBlockingSync flag stalled the ten-proofs-in-flight bench outright — measured, round 3.)
+inline hipError_t zk_host_wait(amdzk_ctx* ctx, hipStream_t s) {
+  const amdzk_ctx* root = ctx->parent ? ctx->parent : ctx;
+  if (!root->host_wait_block) return hipStreamSynchronize(s);
+  hipError_t e = hipSuccess;
+  if (!ctx->wait_evt) e = hipEventCreateWithFlags(&ctx->wait_evt, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventRecord(ctx->wait_evt, s);
+  if (e != hipSuccess) return e;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    e = hipEventQuery(ctx->wait_evt);
+    if (e != hipErrorNotReady) return e;
+    if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(20)) {
+      std::this_thread::yield();
+    } else {
+      std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+  }
+}
 
 int zk_ws_reserve(amdzk_ctx* ctx, int slot, size_t bytes, void** out);
 int zk_pinned_reserve(amdzk_ctx* ctx, size_t bytes, void** out);

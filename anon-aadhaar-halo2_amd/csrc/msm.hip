@@ -562,7 +562,7 @@ static int srs_build(amdzk_ctx* ctx, const void* g, const void* g_lagrange, bool
     const size_t count = (size_t)s->W * s->n;  // all windows are built: switch the whole table to radix 2^261
     ZK_LAUNCH(ctx, "msm_table_to_r261", table_to_r261_kernel, dim3((unsigned)((count + 255) / 256)), block, 0, s->table[b], count);
   }
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // source buffers may be released by the caller
+  ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));  // source buffers may be released by the caller
   *out = s;
   return AMDZK_OK;
 }
@@ -726,7 +726,7 @@ int zk_srs_write(amdzk_ctx* ctx, const amdzk_srs* s, const uint8_t g2[64], const
   uint32_t k = s->k;
   memcpy(out, &k, 4);
   ZK_HIP(ctx, hipMemcpyAsync(out + 4, d, 2 * s->n * 32, hipMemcpyDeviceToHost, ctx->stream));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   if (g2) memcpy(out + 4 + 2 * s->n * 32, g2, 64); else memset(out + 4 + 2 * s->n * 32, 0, 64);
   if (s_g2) memcpy(out + 4 + 2 * s->n * 32 + 64, s_g2, 64); else memset(out + 4 + 2 * s->n * 32 + 64, 0, 64);
   return AMDZK_OK;
@@ -751,7 +751,7 @@ int zk_srs_read(amdzk_ctx* ctx, const uint8_t* data, size_t len, amdzk_srs** out
   ZK_LAUNCH(ctx, "g1_decompress", g1_decompress_kernel, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, d_in, pts, 2 * n, d_err);
   int herr = 0;
   ZK_HIP(ctx, hipMemcpyAsync(&herr, d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   if (herr) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_read: invalid point encoding (not on the curve or x >= q)");
   if (g2_out) memcpy(g2_out, data + 4 + 2 * n * 32, 64);
   if (s_g2_out) memcpy(s_g2_out, data + 4 + 2 * n * 32 + 64, 64);
@@ -783,7 +783,7 @@ int zk_srs_setup(amdzk_ctx* ctx, uint32_t k, const uint64_t s_mont[4], const uin
     t[0] = gen;
     for (int j = 1; j < 256; j++) t[j] = x_to_affine(x_dbl_affine(t[j - 1]));
     ZK_HIP(ctx, hipMemcpyAsync(gtab, t.data(), 256 * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   }
   const uint32_t chunk = 64;
   dim3 pg((unsigned)(((n + chunk - 1) / chunk + 63) / 64)), pb(64);
@@ -800,7 +800,7 @@ int zk_srs_setup(amdzk_ctx* ctx, uint32_t k, const uint64_t s_mont[4], const uin
   ZK_LAUNCH(ctx, "srs_fixed_base_mul", fixed_base_mul_kernel, eg, eb, 0, scal, gtab, gl, n);
   if (g_out) ZK_HIP(ctx, hipMemcpyAsync(g_out, g, n * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream));
   if (g_lagrange_out) ZK_HIP(ctx, hipMemcpyAsync(g_lagrange_out, gl, n * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   return srs_build(ctx, g, gl, true, k, out);
 }
 
@@ -887,7 +887,7 @@ int zk_g_to_lagrange(amdzk_ctx* ctx, const uint64_t* g, uint32_t k, const uint64
   ZK_HIP(ctx, hipMemcpyAsync(dg, g, n * sizeof(G1Affine), hipMemcpyHostToDevice, ctx->stream));
   ZK_TRY(ecfft_to_lagrange(ctx, dg, k, wi, ni, dx, tw, dl));
   ZK_HIP(ctx, hipMemcpyAsync(out, dl, n * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   return AMDZK_OK;
 }
 
@@ -914,7 +914,7 @@ int zk_srs_get(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, uint64_t* out) {
   if (!srs || !out || basis < 0 || basis > 1) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_get: bad argument");
   if (!srs->base[basis]) ZK_FAIL(ctx, AMDZK_E_INVALID, "srs_get: basis %d was not uploaded", basis);
   ZK_HIP(ctx, hipMemcpyAsync(out, srs->base[basis], srs->n * sizeof(G1Affine), hipMemcpyDeviceToHost, ctx->stream));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   return AMDZK_OK;
 }
 
@@ -1106,7 +1106,7 @@ int zk_msm_finish(amdzk_ctx* ctx, const G1X* d_res, size_t ncols, uint64_t* out_
   G1X* h = nullptr;
   ZK_TRY(zk_pinned_reserve(ctx, ncols * sizeof(G1X), (void**)&h));
   ZK_HIP(ctx, hipMemcpyAsync(h, d_res, ncols * sizeof(G1X), hipMemcpyDeviceToHost, ctx->stream));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   std::vector<Fq> pre(ncols);
   Fq acc = Fq::one();
   for (size_t i = 0; i < ncols; i++) {

@@ -131,6 +131,7 @@ __device__ __forceinline__ Fr pack_out(const Fr29& v_below_2p) { return f29_pack
 
 template <bool LAST>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
+  const uint32_t nthreads = blockDim.x;  // a quarter of the tile (one radix-4 group per thread and block), at least 64
   extern __shared__ uint4 lds_raw[];
   uint32_t* L = reinterpret_cast<uint32_t*>(lds_raw);
   const uint32_t tid = threadIdx.x;
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
   const uint32_t log_n = a.log_n;
 
   // ---- stage the sub-transform twiddles: omega_{n_p}^i = omega^(i * n/n_p)
-  for (uint32_t i = tid; i < (rows >> 1); i += NTT_THREADS) tw_st(TW, i, fr29_unpack(ld_fr(a.tw + ((size_t)i << (log_n - a.s)))));
+  for (uint32_t i = tid; i < (rows >> 1); i += nthreads) tw_st(TW, i, fr29_unpack(ld_fr(a.tw + ((size_t)i << (log_n - a.s)))));
 
   // ---- load the tile (whole elements; consecutive lanes read consecutive elements of a contiguous run)
   size_t in_base, row_stride;
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
     in_base = ((size_t)hi << (a.s + a.log_stride)) + lo_base;
     row_stride = (size_t)1 << a.log_stride;
     // element (x, c) at in_base + x*row_stride + c, LDS index x*C + c
-    for (uint32_t e = tid; e < tile; e += NTT_THREADS) {
+    for (uint32_t e = tid; e < tile; e += nthreads) {
       const uint32_t x = e >> a.log_c, c = e & (C - 1);
       const size_t gi = in_base + (size_t)x * row_stride + c;
       Fr v = Fr::zero();
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
     row_stride = a.npass == 1 ? 0 : ((size_t)1 << (log_n - a.log_n1));
     in_base = (size_t)(j1_blk << a.log_c) * row_stride + (a.npass == 3 ? ((size_t)j2 << a.s) : 0);
     // element (rr, x) at in_base + rr*row_stride + x, LDS index x*C + rr
-    for (uint32_t q = tid; q < tile; q += NTT_THREADS) {
+    for (uint32_t q = tid; q < tile; q += nthreads) {
       const uint32_t rr = q >> a.s, x = q & (rows - 1);
       const size_t gi = in_base + (size_t)rr * row_stride + x;
       Fr v = Fr::zero();
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
   // ---- first step only: move into the coset (distribute_powers_zeta) — whole elements
   if (a.pass == 0 && (a.flags & F_IN_COSET)) {
     const Fr29 c1 = fr29_unpack(a.in_c[0]), c2 = fr29_unpack(a.in_c[1]), c0 = fr29_unpack(a.in_c0);
-    for (uint32_t e = tid; e < tile; e += NTT_THREADS) {
+    for (uint32_t e = tid; e < tile; e += nthreads) {
       uint32_t x = e >> a.log_c, c = e & (C - 1);
       size_t gi = LAST ? (in_base + (size_t)c * row_stride + x) : (in_base + (size_t)x * row_stride + c);
       uint32_t m = (uint32_t)(gi % 3);
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
   int st = (int)a.s - 1;
   if (a.s & 1) {  // single round, half-length 2^(s-1): butterfly (x, x + h), twiddle omega_{n_p}^x
     const uint32_t h = 1u << st;
-    for (uint32_t b = tid; b < (tile >> 1); b += NTT_THREADS) {
+    for (uint32_t b = tid; b < (tile >> 1); b += nthreads) {
       const uint32_t c = b & (C - 1), x0 = b >> a.log_c;
       const uint32_t e0 = (x0 << a.log_c) + c, e1 = ((x0 + h) << a.log_c) + c;
       const Fr29 u = lds_ld(L, e0), v = lds_ld(L, e1);
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
     const uint32_t hq = 1u << (st - 1);  // distance between the four elements of a group
     const uint32_t estep = hq << a.log_c;
     const bool last_block = st == 1;
-    for (uint32_t q = tid; q < (tile >> 2); q += NTT_THREADS) {
+    for (uint32_t q = tid; q < (tile >> 2); q += nthreads) {
       const uint32_t c = q & (C - 1), gq = q >> a.log_c;
       const uint32_t lo = gq & (hq - 1), hi = gq >> (st - 1);
       const uint32_t e0 = ((((hi << 2) << (st - 1)) | lo) << a.log_c) + c, e1 = e0 + estep, e2 = e1 + estep, e3 = e2 + estep;
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
     const uint32_t J_prev = hi;  // step 0: hi = 0; step 1 of 3: hi = j1
     const uint32_t log_g = log_n - (a.log_prev + a.s + a.log_next);
     const uint32_t sh_next = a.log_stride - a.log_next;
-    for (uint32_t e = tid; e < tile; e += NTT_THREADS) {
+    for (uint32_t e = tid; e < tile; e += nthreads) {
       uint32_t j = e >> a.log_c, c = e & (C - 1);
       Fr29 x = lds_ld(L, (brev(j, a.s) << a.log_c) + c);
       uint32_t i_next = (lo_base + c) >> sh_next;
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
     const size_t out_base = (size_t)(j1_blk << a.log_c) + (a.npass == 3 ? ((size_t)j2 << a.log_n1) : 0);
     const uint32_t log_ostride = log_n - a.s;  // N_{P-1}
     const Fr29 oc0 = fr29_unpack(a.out_c[0]), oc1 = fr29_unpack(a.out_c[1]), oc2 = fr29_unpack(a.out_c[2]);
-    for (uint32_t e = tid; e < tile; e += NTT_THREADS) {
+    for (uint32_t e = tid; e < tile; e += nthreads) {
       uint32_t j = e >> a.log_c, rr = e & (C - 1);
       Fr29 x = lds_ld(L, (brev(j, a.s) << a.log_c) + rr);
       size_t oi = out_base + rr + ((size_t)j << log_ostride);
@@ -452,7 +453,9 @@ int zk_ntt_ex(amdzk_ctx* ctx, const Fr* d_in, size_t in_stride, Fr* d_out, size_
       if (last && tabs->out_tab) a.flags |= F_OUT_TABLE;
     }
     const uint32_t tile_elems_log = a.s + a.log_c;
-    dim3 grid((uint32_t)(n >> tile_elems_log), (uint32_t)ncols, nz), block(NTT_THREADS);
+    uint32_t threads = (uint32_t)1 << (tile_elems_log > 2 ? tile_elems_log - 2 : 0);
+    threads = threads < 64 ? 64 : threads > (uint32_t)NTT_THREADS ? (uint32_t)NTT_THREADS : threads;
+    dim3 grid((uint32_t)(n >> tile_elems_log), (uint32_t)ncols, nz), block(threads);
     const size_t tile_elems = (size_t)1 << tile_elems_log;
     size_t shmem = (tile_elems + (tile_elems >> 5) + 1 + ((size_t)1 << a.s) / 2 + 1) * 9 * sizeof(uint32_t);  // limbs + skew slots, see ntt_step_kernel
     if (last) {

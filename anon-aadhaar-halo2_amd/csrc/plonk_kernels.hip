@@ -588,9 +588,19 @@ constexpr uint32_t LC_CHUNK = 256;
 // multiply-adds per term, a carry pass every six terms — and reduced once per chunk of coefficients (fp29.cuh
 // f29_wide_*): sum_j (d_j * 2^256)(c_j * 2^261) * 2^-261 = (sum_j d_j c_j) * 2^256. 109 instructions per term against
 // 308 for product + pack + modular add. T < 256 p^2 per chunk, so the reduction comes out below 2.6p.
+// blockIdx.y = part: with gridDim.y > 1 the m terms are cut into gridDim.y runs of `per_part` and part p writes ITS sum to
+// out + p * part_stride (lincomb_sum_parts_kernel adds the parts up): a combination of hundreds of polynomials of 2^15
+// coefficients is otherwise 128 workgroups walking the whole list one term at a time.
 __global__ __launch_bounds__(256) void lincomb_kernel(const Fr* const* polys, const Fr* coefs, uint32_t m, Fr* out, size_t n,
-                                                      int accumulate) {
+                                                      int accumulate, uint32_t per_part, size_t part_stride) {
   __shared__ uint32_t c261[LC_CHUNK][9];  // the chunk's coefficients in radix 2^261, as limbs (every lane reads the same entry)
+  if (gridDim.y > 1) {
+    const uint32_t first_term = blockIdx.y * per_part;
+    polys += first_term;
+    coefs += first_term;
+    m = first_term < m ? min(per_part, m - first_term) : 0;
+    out += (size_t)blockIdx.y * part_stride;
+  }
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   const size_t first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   // every thread of the block walks the same number of rounds, so the barriers below are uniform
@@ -617,6 +627,14 @@ __global__ __launch_bounds__(256) void lincomb_kernel(const Fr* const* polys, co
       const Fr part = f29_pack_canonical<FrP>(f29_reduce_weak(f29_wide_redc<Fr29P>(w)));
       st_fr(out + i, (accumulate || j0 != 0) ? add(ld_fr(out + i), part) : part);
     }
+  }
+}
+// out[i] (+)= sum_p parts[p * stride + i]
+__global__ __launch_bounds__(256) void lincomb_sum_parts_kernel(const Fr* parts, size_t stride, uint32_t nparts, Fr* out, size_t n, int accumulate) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    Fr acc = ld_fr(parts + i);
+    for (uint32_t p = 1; p < nparts; p++) acc = add(acc, ld_fr(parts + (size_t)p * stride + i));
+    st_fr(out + i, accumulate ? add(ld_fr(out + i), acc) : acc);
   }
 }
 __global__ __launch_bounds__(256) void scale_kernel(Fr* a, size_t n, Fr c) {
@@ -917,7 +935,18 @@ int zk_lincomb(amdzk_ctx* ctx, const Fr* const* d_polys, const Fr* d_coefs, uint
   }
   unsigned gx = (unsigned)((n + 255) / 256);
   if (gx > 2048) gx = 2048;
-  ZK_LAUNCH(ctx, "lincomb", lincomb_kernel, dim3(gx), dim3(256), 0, d_polys, d_coefs, m, d_out, n, accumulate ? 1 : 0);
+  // few rows, many terms: parts of >= 32 terms until the launch has ~2048 workgroups
+  uint32_t nparts = 1;
+  while (nparts < 16 && (size_t)gx * nparts * 2 <= 2048 && m / (nparts * 2) >= 32) nparts *= 2;
+  if (nparts == 1) {
+    ZK_LAUNCH(ctx, "lincomb", lincomb_kernel, dim3(gx), dim3(256), 0, d_polys, d_coefs, m, d_out, n, accumulate ? 1 : 0, m, (size_t)0);
+    return AMDZK_OK;
+  }
+  Fr* parts = nullptr;
+  ZK_TRY(zk_ws_reserve(ctx, 4, (size_t)nparts * n * sizeof(Fr), (void**)&parts));  // slot 4 is also kate_div's: stream order keeps them apart
+  const uint32_t per_part = (m + nparts - 1) / nparts;
+  ZK_LAUNCH(ctx, "lincomb", lincomb_kernel, dim3(gx, nparts), dim3(256), 0, d_polys, d_coefs, m, parts, n, 0, per_part, n);
+  ZK_LAUNCH(ctx, "lincomb_sum_parts", lincomb_sum_parts_kernel, dim3(gx), dim3(256), 0, (const Fr*)parts, n, nparts, d_out, n, accumulate ? 1 : 0);
   return AMDZK_OK;
 }
 
@@ -1016,7 +1045,7 @@ int upload_ptrs_and_frs(amdzk_ctx* ctx, const void* const* ptrs, size_t nptrs, c
   ZK_TRY(zk_ws_reserve(ctx, 6, pbytes + (nfrs + extra_frs) * sizeof(Fr) + 256, (void**)&ws));
   if (nptrs) ZK_HIP(ctx, hipMemcpyAsync(ws, ptrs, nptrs * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
   if (nfrs) ZK_HIP(ctx, hipMemcpyAsync(ws + pbytes, frs, nfrs * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the host arrays belong to the caller
+  ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));  // the host arrays belong to the caller
   *d_ptrs = (void**)ws;
   *d_frs = (Fr*)(ws + pbytes);
   return AMDZK_OK;
@@ -1060,7 +1089,7 @@ int amdzk_eval_poly_dev(amdzk_ctx* ctx, const void* const* d_polys, const uint64
   ZK_TRY(upload_ptrs_and_frs(ctx, d_polys, nq, points, nq, nq, &dp, &df));
   ZK_TRY(zk_poly_eval(ctx, (const Fr* const*)dp, df, df + nq, nq, n));
   ZK_HIP(ctx, hipMemcpyAsync(out, df + nq, nq * sizeof(Fr), hipMemcpyDeviceToHost, ctx->stream));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   return AMDZK_OK;
 }
 

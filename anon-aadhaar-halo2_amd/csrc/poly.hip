@@ -193,7 +193,7 @@ int amdzk_domain_new(amdzk_ctx* ctx, uint32_t j, uint32_t k, amdzk_domain** out)
     ZK_FAIL(ctx, AMDZK_E_NOMEM, "domain_new: hipMalloc failed");
   }
   ZK_HIP(ctx, hipMemcpyAsync(d->d_t_evaluations, d->t_evaluations.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   *out = d;
   return AMDZK_OK;
 }
@@ -201,7 +201,7 @@ int amdzk_domain_new(amdzk_ctx* ctx, uint32_t j, uint32_t k, amdzk_domain** out)
 void amdzk_domain_free(amdzk_ctx* ctx, amdzk_domain* d) {
   ZK_ENTER(ctx);
   if (!d) return;
-  if (ctx) hipStreamSynchronize(ctx->stream);
+  if (ctx) zk_host_wait(ctx, ctx->stream);
   if (d->d_t_evaluations) hipFree(d->d_t_evaluations);
   if (d->d_coset_in) hipFree(d->d_coset_in);
   if (d->d_coset_out) hipFree(d->d_coset_out);
@@ -322,9 +322,9 @@ int zk_quotient_plan(amdzk_ctx* ctx, amdzk_domain* d, uint32_t nc) {
     for (size_t i = 0; i < w.size(); i++) w[i] = fr29_const_to_r261(d->vinv[i]);
     ZK_HIP(ctx, hipMalloc((void**)&d->d_vinv261, w.size() * sizeof(Fr)));
     ZK_HIP(ctx, hipMemcpyAsync(d->d_vinv261, w.data(), w.size() * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `w` is a host temporary
+    ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));  // `w` is a host temporary
   }
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   d->nc = nc;
   return AMDZK_OK;
 }

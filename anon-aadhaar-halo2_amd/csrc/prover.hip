@@ -276,7 +276,7 @@ int h2d_staged(amdzk_ctx* ctx, amdzk_pk* pk, void* d, const void* h, size_t byte
 int d2h(amdzk_ctx* ctx, void* h, const void* d, size_t bytes) {
   if (bytes) {
     ZK_HIP(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   }
   return AMDZK_OK;
 }
@@ -663,7 +663,7 @@ int upload_consts261(amdzk_ctx* ctx, amdzk_pk* pk) {
   for (size_t i = 0; i < c.size(); i++) c[i] = mul(pk->consts[i], k32);
   ZK_TRY(h2d_staged(ctx, pk, pk->d_consts261, c.data(), c.size() * 32));
   // without the pinned staging area the copy above reads `c` asynchronously: finish it before `c` goes away
-  if (!pk->pin || c.size() * 32 > pk->pin_cap) ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (!pk->pin || c.size() * 32 > pk->pin_cap) ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   return AMDZK_OK;
 }
 
@@ -682,7 +682,7 @@ int upload_ypow(amdzk_ctx* ctx, amdzk_pk* pk) {
     cur = mul(cur, y);
   }
   ZK_TRY(h2d_staged(ctx, pk, pk->d_ypow, pw.data(), pw.size() * 32));
-  if (!pk->pin || pw.size() * 32 > pk->pin_cap) ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (!pk->pin || pw.size() * 32 > pk->pin_cap) ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   return AMDZK_OK;
 }
 
@@ -713,7 +713,7 @@ int upload_program(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, bool extended) {
   }
   ZK_TRY(dalloc(ctx, pk, &pr.d_instr, ins.size()));
   ZK_TRY(h2d(ctx, pr.d_instr, ins.data(), ins.size() * sizeof(ExprInstr)));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // `ins` is a host temporary
+  ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));  // `ins` is a host temporary
   return AMDZK_OK;
 }
 
@@ -810,7 +810,7 @@ extern "C" {
 void amdzk_pk_free(amdzk_ctx* ctx, amdzk_pk* pk) {
   ZK_ENTER(ctx);
   if (!pk) return;
-  if (ctx) hipStreamSynchronize(ctx->stream);
+  if (ctx) zk_host_wait(ctx, ctx->stream);
   for (void* p : pk->allocs) hipFree(p);
   if (pk->pin) hipHostFree(pk->pin);
   if (pk->dom) amdzk_domain_free(ctx, pk->dom);
@@ -983,7 +983,7 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
       KG_TRY(h2d(ctx, tmp, src[t]->data(), n * 32));
       KG_TRY(amdzk_lagrange_to_coeff_dev(ctx, pk->dom, tmp, 1, n));
       KG_TRY(zk_coeff_to_cosets_r261(ctx, pk->dom, tmp, n, dst[t], ext, 1));
-      ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
     }
     std::vector<Fr> xc(ext);
     for (uint32_t c = 0; c < pk->nc; c++) {
@@ -995,7 +995,7 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
       }
     }
     KG_TRY(h2d(ctx, pk->x_coset, xc.data(), ext * 32));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   }
   // ---- fixed columns and permutation polynomials
   if (F) {
@@ -1036,7 +1036,7 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
         sig[(size_t)i * n + j] = mul(dpow[pi], op[pj]);
       }
     KG_TRY(h2d(ctx, pk->sigma_lag, sig.data(), (size_t)S * n * 32));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
     KG_TRY(d2d(ctx, pk->sigma_poly, pk->sigma_lag, (size_t)S * n * 32));
     KG_TRY(amdzk_lagrange_to_coeff_dev(ctx, pk->dom, pk->sigma_poly, S, n));
     KG_TRY(zk_coeff_to_cosets_r261(ctx, pk->dom, pk->sigma_poly, n, pk->sigma_coset, ext, S));
@@ -1075,7 +1075,7 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
     KG_TRY(dalloc(ctx, pk, &pk->d_cols_ext, ex.size()));
     KG_TRY(h2d(ctx, pk->d_cols_lag, lag.data(), lag.size() * sizeof(Fr*)));
     KG_TRY(h2d(ctx, pk->d_cols_ext, ex.data(), ex.size() * sizeof(Fr*)));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   }
 
   // ---- programs
@@ -1100,7 +1100,7 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
     for (uint32_t l = 0; l < L; l++) outs[2 * l] = pk->ci + (size_t)l * n, outs[2 * l + 1] = pk->ct + (size_t)l * n;
     KG_TRY(dalloc(ctx, pk, &pk->d_outs_compress, outs.size()));
     KG_TRY(h2d(ctx, pk->d_outs_compress, outs.data(), outs.size() * sizeof(Fr*)));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   }
   // (2) permutation fractions: den[s] -> scratch column s (inverted later), num[s] -> frac column s
   {
@@ -1138,7 +1138,7 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
     for (uint32_t s = 0; s < ns; s++) outs[2 * s] = pk->frac + (size_t)s * n, outs[2 * s + 1] = pk->zp() + (size_t)s * n;
     KG_TRY(dalloc(ctx, pk, &pk->d_outs_pfrac, outs.size()));
     KG_TRY(h2d(ctx, pk->d_outs_pfrac, outs.data(), outs.size() * sizeof(Fr*)));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   }
   // (3) lookup fractions: den = (a'+beta)(s'+gamma) -> frac2[l]; num = (ci+beta)(ct+gamma) -> zl[l]
   {
@@ -1169,7 +1169,7 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
     for (uint32_t l = 0; l < L; l++) outs[2 * l] = pk->frac2 + (size_t)l * n, outs[2 * l + 1] = pk->zl() + (size_t)l * n;  // frac2: beside the permutation products
     KG_TRY(dalloc(ctx, pk, &pk->d_outs_lfrac, outs.size()));
     KG_TRY(h2d(ctx, pk->d_outs_lfrac, outs.data(), outs.size() * sizeof(Fr*)));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   }
   // (4) the h(X) numerator: gates, permutation, lookups — evaluation.rs evaluate_h order
   {
@@ -1279,7 +1279,7 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
   KG_TRY(dalloc(ctx, pk, &pk->d_consts, pk->consts.size()));
   KG_TRY(h2d(ctx, pk->d_consts, pk->consts.data(), pk->consts.size() * 32));
   KG_TRY(dalloc(ctx, pk, &pk->d_consts261, pk->consts.size()));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   KG_TRY(upload_program(ctx, pk, pk->prog_compress, false));
   KG_TRY(upload_program(ctx, pk, pk->prog_pfrac, false));
   KG_TRY(upload_program(ctx, pk, pk->prog_lfrac, false));
@@ -1311,7 +1311,7 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
   // l_active coset = 1 - (l_last + l_blind): lactive_c holds l_blind's coset; tiny one-off program
   {
     KG_TRY(upload_consts261(ctx, pk));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
     Program pr;
     pr.op(OP_PUSH_CONST, pk->c_one); pr.push();
     pr.op(OP_SUB_COL, COL(pk->se_llast(), r0));
@@ -1323,9 +1323,9 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
     KG_TRY(dalloc(ctx, pk, &d_out, 1));
     Fr* tgt = pk->lactive_c;
     KG_TRY(h2d(ctx, d_out, &tgt, sizeof(Fr*)));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
     KG_TRY(run_program(ctx, pk, pr, true, d_out, nullptr, "expr_l_active"));
-    ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   }
 #undef KG_TRY
   *out = pk;
@@ -1471,7 +1471,7 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
   double tlast = tnow();
   auto tick = [&](const char* label) {
     if (!ttrace) return;
-    hipStreamSynchronize(ctx->stream);
+    zk_host_wait(ctx, ctx->stream);
     double t = tnow();
     fprintf(stderr, "[amdzk-time] %-28s %8.3f ms\n", label, t - tlast);
     tlast = t;
@@ -1567,7 +1567,7 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
       }
       ZK_TRY(h2d_staged(ctx, pk, pk->inst() + (size_t)c * n, iv.data(), len * 32));
       // without room in the pinned staging area the copy reads `iv` asynchronously: finish it before the next column reuses it
-      if (!pk->pin || len * 32 > pk->pin_cap) ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (!pk->pin || len * 32 > pk->pin_cap) ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
     }
   }
   // The random polynomial of the vanishing argument (step 5 below) depends on nothing but the RNG: its n draws follow
@@ -2096,7 +2096,7 @@ int amdzk_quotient_eval_dev(amdzk_ctx* ctx, amdzk_pk* pk, const void* d_polys, s
   }
   ZK_TRY(quotient_pieces(ctx, pk));
   ZK_TRY(d2d(ctx, d_pieces_out, pk->hpieces, (size_t)pk->qdeg * pk->n * 32));
-  ZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   return AMDZK_OK;
 }
 

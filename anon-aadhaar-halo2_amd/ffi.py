@@ -74,6 +74,7 @@ def lib():
         "amdzk_coeff_to_extended_dev": (i32, [vp, vp, vp, sz, vp, sz, sz]),
         "amdzk_extended_to_coeff_dev": (i32, [vp, vp, vp, sz, sz]),
         "amdzk_divide_by_vanishing_dev": (i32, [vp, vp, vp, sz, sz]),
+        "amdzk_set_host_wait": (i32, [vp, i32]),
         "amdzk_keygen": (i32, [vp, vp, vp, vp, vp, vp, C.POINTER(vp)]),
         "amdzk_keygen_ex": (i32, [vp, vp, vp, vp, vp, vp, u32, C.POINTER(vp)]),
         "amdzk_pk_free": (None, [vp, vp]),
@@ -197,6 +198,10 @@ class Context:
 
     def sync(self):
         self._chk(self.L.amdzk_sync(self.h))
+
+    def set_host_wait(self, block):
+        """amdzk_set_host_wait: block=True, waits sleep on a blocking-sync event; False, they spin (the default)."""
+        self._chk(self.L.amdzk_set_host_wait(self.h, 1 if block else 0))
 
     def device(self):
         return self.L.amdzk_ctx_device(self.h)

@@ -72,6 +72,10 @@ def parse_args(argv=None):
     ap.add_argument("--regions", type=int, default=5, help="how many times the timed region (--steps proofs per GPU) runs; the median is reported")
     ap.add_argument("--host-cores", type=int, default=0,
                     help="confine this rank to the first N cores of its affinity mask (sched_setaffinity before any GPU call); 0 = leave it alone")
+    ap.add_argument("--host-wait", default="auto", choices=("auto", "spin", "block"),
+                    help="how the per-proof driver threads wait for the GPU during the timed steps: spin (hipStreamSynchronize), block "
+                         "(poll a completion event with 50-us sleeps), auto = block with 4 or more proofs in flight: same rate on 16 cores for a sixth of "
+                         "the CPU time, and 73 instead of 63 proofs/s on 2 cores (profiles/r03e_host_wait_and_cu_mask.txt)")
     ap.add_argument("--no-k22", action="store_true", help="skip BASELINE config 5 (2^22-point MSM and NTT, config.k22_stress) and the CPU kernel baselines")
     return ap.parse_args(argv)
 
@@ -396,6 +400,11 @@ def run_rank(args):
         for r in range(max(args.warmup, 0)):
             prover.prove(cx, (cx + r) % nw, 1000 * rank + 500000 + r * P + cx)
 
+    # host waits: with more proofs in flight than cores to spare the driver threads sleep instead of spinning
+    block_waits = args.host_wait == "block" or (args.host_wait == "auto" and P >= 4)
+    if not stub:
+        for cx in prover.ctxs:
+            cx.set_host_wait(block_waits)
     run_pool(P, list(range(P)), warm_context)
     prover.check_affinity()
     # the timed region, R times over: same steps, fresh blinding seeds; region 0's proofs are the ones gathered and
@@ -453,6 +462,7 @@ def run_rank(args):
         # single-proof latency: one proof alone on the GPU, no per-kernel events (median of 3); then the same with a
         # serial-mode key (one stream), whose proof must be the same bytes
         prover.sync()
+        prover.ctx.set_host_wait(False)  # one proof alone: spinning waits are the low-latency choice
         lat_ms, ref = prover.latency(777001, serial=False)
         if not args.no_serial_latency:
             lat_serial_ms, other = prover.latency(777001, serial=True)
@@ -488,6 +498,7 @@ def run_rank(args):
                            "timed_regions": len(regions),
                            "host_cpu_s_per_proof": round(host_cpu_s / steps, 5), "host_threads": min(P, steps) + 1,
                            "host_cores_allowed": cores_allowed,
+                           "host_wait": "block (driver threads poll a completion event with 50-us sleeps)" if block_waits else "spin (hipStreamSynchronize)",
                            "host_note": "rank 0's process CPU time (all threads) over the median region / its proofs; one host thread "
                                         "per proof in flight, blocked in the HIP runtime while the GPU works",
                            "single_proof_latency_ms": round(lat_ms, 3) if lat_ms else None,

@@ -70,6 +70,13 @@ int amdzk_set_stream(amdzk_ctx* ctx, void* hip_stream);
 int amdzk_ctx_device(const amdzk_ctx* ctx);
 int amdzk_ctx_check_affinity(amdzk_ctx* ctx);
 int amdzk_ptr_check_affinity(amdzk_ctx* ctx, const void* dptr);
+/* How this context's calls wait for the device: AMDZK_WAIT_SPIN (default; hipStreamSynchronize — lowest latency, the
+ * waiting thread keeps a core busy) or AMDZK_WAIT_BLOCK (the thread sleeps on a blocking-sync event: for hosts that keep
+ * more proofs in flight than they have cores to spare — one GPU's share of an 8-GPU host is 2 cores on the reference box,
+ * where spinning costs 17 % of the rate). Default from AMDZK_HOST_WAIT=spin|block when the ctx is made. */
+#define AMDZK_WAIT_SPIN 0
+#define AMDZK_WAIT_BLOCK 1
+int amdzk_set_host_wait(amdzk_ctx* ctx, int mode);
 int amdzk_sync(amdzk_ctx* ctx);
 
 /* ---- device memory (plain hipMalloc'd bytes; any device pointer of the same GPU is accepted by
