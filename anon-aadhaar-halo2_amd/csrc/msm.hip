@@ -399,27 +399,34 @@ __global__ __launch_bounds__(64) void msm_accum_final_kernel(const uint32_t* off
 // rows[col][g] = sum_r dense[col][64g + r],  cols[col][r] = sum_g dense[col][64g + r].
 // Lane-parallel serial sums, no shuffles: the prover is bound by instruction issue, and a 64-lane shuffle tree
 // spends 6 wave-level point additions to add 64 values that a lane-per-output loop adds in 63 for all 64
-// outputs at once. One workgroup of four wavefronts per "unit": unit 0 computes the 64 column sums (lane = r,
-// each wavefront a quarter of the g range), unit u >= 1 the row sums of g in [64(u-1), 64u) (lane = g, each
-// wavefront 16 of the 64 r); the three partial results meet in LDS. ~134 wave-level additions per column at
-// c = 13 instead of 832.
-__global__ __launch_bounds__(256) void msm_rowcol_kernel(const G1X29* dense, uint32_t nb, G1X29* rows, G1X29* cols) {
-  __shared__ G1X29 part[3][64];
+// outputs at once. One workgroup of ROWCOL_WAVES wavefronts per "unit": unit 0 computes the 64 column sums (lane = r,
+// each wavefront 1 / ROWCOL_WAVES of the g range), unit u >= 1 the row sums of g in [64(u-1), 64u) (lane = g, each
+// wavefront 64 / ROWCOL_WAVES of the 64 r); the partial results meet in LDS, pairwise. The kernel is a handful of
+// workgroups per column and pure latency — a point addition is ~6.5 us of dependent products — and it sits on the
+// transcript's chain at the end of every commitment batch, so what counts is its DEPTH: 8 + 3 additions with eight
+// wavefronts (round 3) against 16 + 3 with four.
+constexpr uint32_t ROWCOL_WAVES = 8;
+__global__ __launch_bounds__(64 * ROWCOL_WAVES) void msm_rowcol_kernel(const G1X29* dense, uint32_t nb, G1X29* rows, G1X29* cols) {
+  __shared__ G1X29 part[ROWCOL_WAVES / 2][64];
   const uint32_t col = blockIdx.y, unit = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t G = nb >> 6;
   const G1X29* d = dense + (size_t)col * nb;
   const uint32_t g_row = (unit - 1) * 64 + lane;  // unit >= 1 only
   G1X29 acc = G1X29::inf();
   if (unit == 0) {
-    const uint32_t per = (G + 3) / 4, g0 = wv * per, g1 = min(G, g0 + per);
+    const uint32_t per = (G + ROWCOL_WAVES - 1) / ROWCOL_WAVES, g0 = wv * per, g1 = min(G, g0 + per);
     for (uint32_t g = g0; g < g1; g++) acc = x29_add(acc, ld_x29(d + 64 * g + lane));
   } else if (g_row < G) {
-    for (uint32_t r = 16 * wv; r < 16 * wv + 16; r++) acc = x29_add(acc, ld_x29(d + 64 * g_row + r));
+    constexpr uint32_t per = 64 / ROWCOL_WAVES;
+    for (uint32_t r = per * wv; r < per * wv + per; r++) acc = x29_add(acc, ld_x29(d + 64 * g_row + r));
   }
-  if (wv) part[wv - 1][lane] = acc;
-  __syncthreads();
+  for (uint32_t half = ROWCOL_WAVES / 2; half >= 1; half >>= 1) {  // waves [half, 2 half) hand their sums to waves [0, half)
+    if (wv >= half && wv < 2 * half) part[wv - half][lane] = acc;
+    __syncthreads();
+    if (wv < half) acc = x29_add(acc, part[wv][lane]);
+    __syncthreads();
+  }
   if (wv == 0) {
-    for (uint32_t w = 0; w < 3; w++) acc = x29_add(acc, part[w][lane]);
     if (unit == 0) st_x29(cols + (size_t)col * 64 + lane, acc);
     else if (g_row < G) st_x29(rows + (size_t)col * G + g_row, acc);
   }
@@ -1039,7 +1046,8 @@ static int msm_group(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const MsmG
   }
   ZK_LAUNCH(ctx, "msm_accum_final", msm_accum_final_kernel, dim3(nb / 64, (unsigned)ncols), dim3(64), 0, off[MSM_NLEV], nb, list[MSM_NLEV],
             g.cap[MSM_NLEV], dense);
-  ZK_LAUNCH(ctx, "msm_rowcol", msm_rowcol_kernel, dim3((unsigned)(1 + (g.G + 63) / 64), (unsigned)ncols), dim3(256), 0, dense, nb, rows, cols);
+  ZK_LAUNCH(ctx, "msm_rowcol", msm_rowcol_kernel, dim3((unsigned)(1 + (g.G + 63) / 64), (unsigned)ncols), dim3(64 * ROWCOL_WAVES), 0, dense, nb, rows,
+            cols);
   const unsigned fold_w = (unsigned)((g.G + 63) / 64);  // 1, 2, 4 or 8 (c <= 16)
   const int fold_split = fold_w <= 4;                    // at most 9 wavefronts per workgroup either way (launch bound 576)
   ZK_LAUNCH(ctx, "msm_fold", msm_fold_kernel, dim3((unsigned)ncols), dim3(64 * ((fold_split ? 2 : 1) * fold_w + 1)), 0, rows, cols, nb, outp,

@@ -84,10 +84,11 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_kernel(ExprArgs a) {
   Fr tos = Fr::zero();
   uint32_t sp = 0;  // elements on the stack, including tos
   const size_t blk_base = row & ~a.mask;
-  const ExprProgPtr prog = (ExprProgPtr)a.prog;
+  const uint32_t first = a.nparts ? a.part_start[blockIdx.y] : 0u, prog_len = a.nparts ? a.part_len[blockIdx.y] : a.prog_len;
+  const ExprProgPtr prog = (ExprProgPtr)a.prog + first;
   ExprWord cur = expr_word(prog, 0), nxt = expr_word(prog, 1);
   Fr pre = expr_fetch(cur, row, blk_base, a.mask);
-  for (uint32_t pc = 0; pc < a.prog_len; pc++) {
+  for (uint32_t pc = 0; pc < prog_len; pc++) {
     const uint32_t op = cur.op_arg >> 24, arg = cur.op_arg & 0xffffffu;
     const Fr v = pre;  // operand of this instruction (if it has one), fetched one instruction ago
     const ExprWord nn = expr_word(prog, pc + 2);
@@ -132,6 +133,14 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_kernel(ExprArgs a) {
         st_fr(a.outs[arg] + row, tos);
         sp--;
         if (sp > 0) tos = stack[(sp - 1) * EXPR_THREADS + tid];
+        break;
+      case OP_PICK:  // entry `arg` below the top; the old top sinks into LDS first (arg = 0 then reads it back: a dup)
+        stack[(sp - 1) * EXPR_THREADS + tid] = tos;
+        tos = stack[(sp - 1 - arg) * EXPR_THREADS + tid];
+        sp++;
+        break;
+      case OP_NIP:
+        sp -= arg;
         break;
       default:
         break;
@@ -303,6 +312,14 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_limbs_kernel(ExprArgs 
         st_fr(a.outs[arg] + row, f29_pack_canonical<FrP>(tos));
         sp--;
         if (sp > 0) tos = lds_ld29(stack, sp - 1, tid);
+        break;
+      case OP_PICK:
+        lds_st29(stack, sp - 1, tid, tos);
+        tos = lds_ld29(stack, sp - 1 - arg, tid);
+        sp++;
+        break;
+      case OP_NIP:
+        sp -= arg;
         break;
       default:
         break;
@@ -867,8 +884,9 @@ __global__ void scatter_rows_kernel(Fr* dst, size_t col_stride, size_t row0, con
 // ------------------------------------------------------------------------------ launch wrappers
 int zk_expr_eval(amdzk_ctx* ctx, const ExprArgs& a, uint32_t depth, const char* name) {
   size_t shmem = (size_t)(depth ? depth : 1) * EXPR_THREADS * sizeof(Fr);
-  const dim3 grid((unsigned)((a.nrows + EXPR_THREADS - 1) / EXPR_THREADS)), block(EXPR_THREADS);
+  const dim3 grid((unsigned)((a.nrows + EXPR_THREADS - 1) / EXPR_THREADS), a.nparts ? a.nparts : 1u), block(EXPR_THREADS);
   if (a.radix261) ZK_FAIL(ctx, AMDZK_E_INVALID, "expr_eval: radix-2^261 programs run on the limb-resident interpreter");
+  if (a.nparts > (uint32_t)EXPR_MAX_PARTS) ZK_FAIL(ctx, AMDZK_E_INVALID, "expr_eval: too many program parts");
   if (shmem > 65536) ZK_HIP(ctx, hipFuncSetAttribute((const void*)expr_eval_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   ZK_LAUNCH(ctx, name, expr_eval_kernel, grid, block, shmem, a);
   return AMDZK_OK;

@@ -35,9 +35,14 @@ enum ExprOp : uint32_t {
   OP_WACC = 20,         // wide += pop() * y^(K-1-j), j = arg & 0x7fffff (ExprInstr::ptr: that power, radix 2^261);
                         // arg bit 23: move the columns' carries up with this term (every sixth term of a group)
   OP_WFLUSH = 21,       // h_out[row] (+)= reduce(wide) * hot[arg & 7]  (4: no factor);  wide = 0;  arg & 16: first group (=, not +=)
+  // ---- both interpreters: values shared by several factors stay on the stack and are copied from there (the permutation
+  // argument's w_j = (v_j + gamma) / beta serves sigma_j + w_j AND delta^j X + w_j: one product per column instead of two)
+  OP_PICK = 22,         // push a copy of the entry `arg` below the top (0: the top itself)
+  OP_NIP = 23,          // discard the `arg` entries below the top; the top stays
 };
 
 constexpr int EXPR_HOT = 4;
+constexpr int EXPR_MAX_PARTS = 8;
 constexpr uint32_t EXPR_NO_SLOT = 0xffffffffu;
 
 // One resolved instruction (16 bytes, fetched with a single scalar load): op << 24 | arg, the row
@@ -64,6 +69,12 @@ struct ExprArgs {
   // 1: everything the program touches is in radix 2^261 (32 x the value in the ordinary form): products use
   //    fp29.cuh's in-place 29-bit product. The prover runs the h(X) program this way (extended domain only).
   uint32_t radix261;
+  // Lagrange-domain programs only (expr_eval_kernel): the program as `nparts` independent pieces (each leaves the
+  // stack empty), piece p = instructions [part_start[p], part_start[p] + part_len[p]), run by the workgroups with
+  // blockIdx.y = p. n = 2^15 rows are 512 wavefronts — half a wavefront per SIMD walking a long program one dependent
+  // product after the other; cut at set / lookup boundaries the same work is 8 x as many wavefronts. 0: the whole program.
+  uint32_t nparts;
+  uint32_t part_start[EXPR_MAX_PARTS], part_len[EXPR_MAX_PARTS];
 };
 
 int zk_expr_eval(amdzk_ctx* ctx, const ExprArgs& a, uint32_t depth, const char* name);

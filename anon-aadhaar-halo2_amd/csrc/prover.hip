@@ -74,7 +74,20 @@ struct Program {
   uint32_t depth = 0, cur = 0;
   bool uses_hot = false;
   ExprInstr* d_instr = nullptr;  // resolved instructions (device)
-  void op(uint32_t o, uint32_t arg = 0) { words.push_back((o << 24) | (arg & 0xffffffu)); }
+  // Lagrange-domain programs: instruction indices at which an independent piece starts (the stack is empty there):
+  // run_program cuts the program there into up to EXPR_MAX_PARTS parts that run side by side (ExprArgs::nparts)
+  std::vector<uint32_t> piece_starts;
+  void piece() { piece_starts.push_back((uint32_t)words.size()); }
+  // h(X) programs: term j (closed by the j-th OP_ACC) carries the factor beta^term_beta[j] in its power of y
+  std::vector<uint32_t> term_beta;
+  uint32_t next_beta = 0;
+  void op(uint32_t o, uint32_t arg = 0) {
+    words.push_back((o << 24) | (arg & 0xffffffu));
+    if (o == OP_ACC) {
+      term_beta.push_back(next_beta);
+      next_beta = 0;
+    }
+  }
   void push() {
     cur++;
     if (cur > depth) depth = cur;
@@ -136,7 +149,7 @@ struct amdzk_pk {
   uint32_t num_gates = 0;
   std::vector<std::pair<uint32_t, uint32_t>> lookup_shape;  // (#inputs, #tables); expressions follow the gates in order
   std::vector<Fr> consts;                                   // circuit constants, then the dynamic ones
-  uint32_t c_one = 0, c_theta = 0, c_beta = 0, c_gamma = 0, c_y = 0, c_bdelta = 0;
+  uint32_t c_one = 0, c_theta = 0, c_beta = 0, c_gamma = 0, c_y = 0, c_betainv = 0;
   amdzk_domain* dom = nullptr;
   const amdzk_srs* srs = nullptr;
   Fr transcript_repr, omega, omega_inv;
@@ -146,6 +159,12 @@ struct amdzk_pk {
   Fr *fixed_lag = nullptr, *fixed_poly = nullptr, *fixed_coset = nullptr;
   Fr *sigma_lag = nullptr, *sigma_poly = nullptr, *sigma_coset = nullptr;
   Fr *l0_c = nullptr, *llast_c = nullptr, *lactive_c = nullptr, *x_coset = nullptr, *omega_pow = nullptr;
+  // delta^j * omega^i ([S][n], Lagrange) and delta^j * X on the quotient cosets ([S][ext], radix 2^261): the identity
+  // permutation's columns. With them v + beta delta^j X + gamma = beta (delta^j X + w), w = (v + gamma) / beta — the SAME w
+  // that serves v + beta sigma + gamma = beta (sigma + w): three products per permutation column instead of four, in
+  // the Lagrange-domain fractions and in h(X) (the beta^m of a set cancels in a fraction and rides on the term's power of y).
+  Fr *dxw_lag = nullptr, *dx_coset = nullptr;
+  std::vector<uint32_t> h_term_beta_pow;  // per term of the h(X) program: the power of beta its power of y is multiplied by
   // device: per-proof workspace. poly arena order: adv | inst | la | ls | zp | zl
   size_t NP = 0;
   // P: the committed columns' Lagrange values [NP][n] (what commit_lagrange and the Lagrange-domain programs read);
@@ -228,7 +247,8 @@ struct amdzk_pk {
   uint32_t sl_la(uint32_t l) { return F + A + I + S + 2 * L + l; }
   uint32_t sl_ls(uint32_t l) { return F + A + I + S + 3 * L + l; }
   uint32_t sl_omega() { return F + A + I + S + 4 * L; }
-  uint32_t nslots_lag() { return F + A + I + S + 4 * L + 1; }
+  uint32_t sl_dxw(uint32_t c) { return F + A + I + S + 4 * L + 1 + c; }
+  uint32_t nslots_lag() { return F + A + I + 2 * S + 4 * L + 1; }
   // slots, extended table
   uint32_t se_sigma(uint32_t c) { return F + A + I + c; }
   uint32_t se_zp(uint32_t s) { return F + A + I + S + s; }
@@ -239,7 +259,8 @@ struct amdzk_pk {
   uint32_t se_llast() { return se_l0() + 1; }
   uint32_t se_lactive() { return se_l0() + 2; }
   uint32_t se_x() { return se_l0() + 3; }
-  uint32_t nslots_ext() { return se_l0() + 4; }
+  uint32_t se_dx(uint32_t c) { return se_l0() + 4 + c; }
+  uint32_t nslots_ext() { return se_l0() + 4 + S; }
 };
 
 namespace {
@@ -616,6 +637,15 @@ uint32_t finalize_limb_program(Program& pr) {
         tail.insert(tail.end(), out.begin(), out.end());
         out.clear();
         break;
+      case OP_PICK:  // a copy of the entry `arg` below the top; the top sinks into the LDS stack
+        if (st.back() > 8.0) reduce_tos();
+        emit(op, arg);
+        st.push_back(st[st.size() - 1 - arg]);
+        break;
+      case OP_NIP:
+        emit(op, arg);
+        st.erase(st.end() - 1 - arg, st.end() - 1);
+        break;
       default:
         emit(op, arg);
         break;
@@ -676,9 +706,12 @@ int upload_ypow(amdzk_ctx* ctx, amdzk_pk* pk) {
   for (int i = 0; i < 5; i++) k32 = add(k32, k32);
   std::vector<Fr> pw(K);
   Fr cur = k32;
-  const Fr y = pk->consts[pk->c_y];
+  const Fr y = pk->consts[pk->c_y], beta = pk->consts[pk->c_beta];
+  std::vector<Fr> bpow = {Fr::one()};  // beta^m for the terms whose factor beta^m was taken out (the permutation products)
   for (uint32_t j = K; j-- > 0;) {
-    pw[j] = cur;
+    const uint32_t m = j < pk->h_term_beta_pow.size() ? pk->h_term_beta_pow[j] : 0;
+    while (bpow.size() <= m) bpow.push_back(mul(bpow.back(), beta));
+    pw[j] = m ? mul(cur, bpow[m]) : cur;
     cur = mul(cur, y);
   }
   ZK_TRY(h2d_staged(ctx, pk, pk->d_ypow, pw.data(), pw.size() * 32));
@@ -730,6 +763,22 @@ int run_program(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, bool extended, Fr* co
   // zk_coeff_to_cosets_r261, their constants from d_consts261, and the result goes back through
   // zk_cosets_to_pieces. Lagrange-domain programs read the caller's radix-2^256 witness as is.
   a.radix261 = extended ? 1u : 0u;
+  a.nparts = 0;
+  if (!extended && pr.piece_starts.size() > 1) {  // balanced by instruction count, cut at piece boundaries only
+    const uint32_t total = (uint32_t)pr.words.size(), want = std::min<uint32_t>(EXPR_MAX_PARTS, (uint32_t)pr.piece_starts.size());
+    uint32_t begin = 0;
+    for (size_t i = 1; i <= pr.piece_starts.size() && a.nparts < want; i++) {
+      const uint32_t end = i < pr.piece_starts.size() ? pr.piece_starts[i] : total;
+      const bool last_part = a.nparts + 1 == want;
+      if ((!last_part && end >= (uint64_t)total * (a.nparts + 1) / want) || (last_part && end == total)) {
+        a.part_start[a.nparts] = begin;
+        a.part_len[a.nparts] = end - begin;
+        a.nparts++;
+        begin = end;
+      }
+    }
+    if (begin != total) a.nparts = 0;  // (cannot happen: the last part runs to the end) — fall back to one part
+  }
   for (int i = 0; i < EXPR_HOT; i++) a.hot[i] = EXPR_NO_SLOT;
   if (extended && pr.uses_hot) {
     a.hot[0] = pk->se_l0();
@@ -737,7 +786,9 @@ int run_program(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, bool extended, Fr* co
     a.hot[2] = pk->se_lactive();
     a.hot[3] = pk->se_x();
   }
-  return extended ? zk_expr_eval_limbs(ctx, a, pr.depth + 1, name) : zk_expr_eval(ctx, a, pr.depth + 1, name);
+  // LDS stack slots: the limb interpreter keeps the top of the stack in registers, so a program whose stack holds at most
+  // pr.depth - 1 values (finalize_limb_program) needs pr.depth - 2 slots: pr.depth - 1 leaves one spare
+  return extended ? zk_expr_eval_limbs(ctx, a, pr.depth > 1 ? pr.depth - 1 : 1, name) : zk_expr_eval(ctx, a, pr.depth + 1, name);
 }
 
 Fr rotate_omega(const amdzk_pk* pk, const Fr& x, int rot) {
@@ -896,7 +947,7 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
   }
   for (uint32_t e = 0; e < c->num_exprs; e++)
     pk->exprs.emplace_back(c->expr_words + c->expr_offsets[e], c->expr_words + c->expr_offsets[e + 1]);
-  // constants: circuit | one theta beta gamma y | beta*delta^j (j < S)
+  // constants: circuit | one theta beta gamma y 1/beta
   pk->consts.resize(c->num_constants);
   if (c->num_constants) memcpy(pk->consts.data(), c->constants, (size_t)c->num_constants * 32);
   pk->c_one = c->num_constants;
@@ -904,8 +955,8 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
   pk->c_beta = pk->c_one + 2;
   pk->c_gamma = pk->c_one + 3;
   pk->c_y = pk->c_one + 4;
-  pk->c_bdelta = pk->c_one + 5;
-  pk->consts.resize(pk->c_bdelta + pk->S, Fr::zero());
+  pk->c_betainv = pk->c_one + 5;
+  pk->consts.resize(pk->c_betainv + 1, Fr::zero());
   pk->consts[pk->c_one] = Fr::one();
 
   const size_t n = pk->n, ext = pk->ext;
@@ -922,6 +973,8 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
   KG_TRY(dalloc(ctx, pk, &pk->lactive_c, ext));
   KG_TRY(dalloc(ctx, pk, &pk->x_coset, ext));
   KG_TRY(dalloc(ctx, pk, &pk->omega_pow, n));
+  KG_TRY(dalloc(ctx, pk, &pk->dxw_lag, (size_t)S * n));
+  KG_TRY(dalloc(ctx, pk, &pk->dx_coset, (size_t)S * ext));
   pk->NP = (size_t)A + I + 2 * L + ns + L;
   KG_TRY(dalloc(ctx, pk, &pk->P, pk->NP * n));
   KG_TRY(dalloc(ctx, pk, &pk->PQ, pk->NP * n));
@@ -996,6 +1049,19 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
     }
     KG_TRY(h2d(ctx, pk->x_coset, xc.data(), ext * 32));
     ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
+    // the identity permutation: delta^j * omega^i (Lagrange) and delta^j * X on the cosets (same radix as x_coset)
+    Fr dj = Fr::one();
+    const Fr delta = fr_delta();
+    for (uint32_t j = 0; j < S; j++) {
+      KG_TRY(d2d(ctx, pk->dxw_lag + (size_t)j * n, pk->omega_pow, n * 32));
+      KG_TRY(d2d(ctx, pk->dx_coset + (size_t)j * ext, pk->x_coset, ext * 32));
+      if (j) {
+        KG_TRY(zk_scale(ctx, pk->dxw_lag + (size_t)j * n, n, dj));
+        KG_TRY(zk_scale(ctx, pk->dx_coset + (size_t)j * ext, ext, dj));
+      }
+      dj = mul(dj, delta);
+    }
+    ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   }
   // ---- fixed columns and permutation polynomials
   if (F) {
@@ -1054,6 +1120,7 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
     for (uint32_t i = 0; i < A; i++) lag[pk->sl_adv(i)] = pk->adv() + (size_t)i * n, ex[pk->sl_adv(i)] = pk->PC + (size_t)i * ext;
     for (uint32_t i = 0; i < I; i++) lag[pk->sl_inst(i)] = pk->inst() + (size_t)i * n, ex[pk->sl_inst(i)] = pk->PC + (size_t)(A + i) * ext;
     for (uint32_t i = 0; i < S; i++) lag[pk->sl_sigma(i)] = pk->sigma_lag + (size_t)i * n, ex[pk->se_sigma(i)] = pk->sigma_coset + (size_t)i * ext;
+    for (uint32_t i = 0; i < S; i++) lag[pk->sl_dxw(i)] = pk->dxw_lag + (size_t)i * n, ex[pk->se_dx(i)] = pk->dx_coset + (size_t)i * ext;
     for (uint32_t l = 0; l < L; l++) {
       lag[pk->sl_ci(l)] = pk->ci + (size_t)l * n;
       lag[pk->sl_ct(l)] = pk->ct + (size_t)l * n;
@@ -1087,6 +1154,7 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
     Program& pr = pk->prog_compress;
     uint32_t e = pk->num_gates;
     for (uint32_t l = 0; l < L; l++) {
+      pr.piece();
       KG_TRY(emit_compressed(ctx, pk, pr, e, pk->lookup_shape[l].first));
       pr.op(OP_STORE, 2 * l);
       pr.pop();
@@ -1102,37 +1170,38 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
     KG_TRY(h2d(ctx, pk->d_outs_compress, outs.data(), outs.size() * sizeof(Fr*)));
     ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   }
-  // (2) permutation fractions: den[s] -> scratch column s (inverted later), num[s] -> frac column s
+  // (2) permutation fractions: den[s] -> frac column s (inverted later), num[s] -> zp column s. Per set: the columns'
+  // w_j = (v_j + gamma) / beta stay on the stack and serve both products, prod_j (sigma_j + w_j) and
+  // prod_j (delta^j omega^row + w_j); the common factor beta^m of numerator and denominator cancels in num / den.
   {
     Program& pr = pk->prog_pfrac;
     for (uint32_t s = 0; s < ns; s++) {
-      uint32_t lo = s * pk->chunk, hi = std::min(S, lo + pk->chunk);
-      for (uint32_t j = lo; j < hi; j++) {  // denominator: prod (v + beta*sigma + gamma)
-        pr.op(OP_PUSH_COL, COL(pk->sl_sigma(j), r0));
+      const uint32_t lo = s * pk->chunk, hi = std::min(S, lo + pk->chunk), m = hi - lo;
+      pr.piece();
+      for (uint32_t j = lo; j < hi; j++) {
+        pr.op(OP_PUSH_COL, COL(colkind_slot_lag(pk->perm_cols[j]), r0));
         pr.push();
-        pr.op(OP_MUL_CONST, pk->c_beta);
-        pr.op(OP_ADD_COL, COL(colkind_slot_lag(pk->perm_cols[j]), r0));
         pr.op(OP_ADD_CONST, pk->c_gamma);
-        if (j > lo) {
-          pr.op(OP_MUL);
-          pr.pop();
-        }
+        pr.op(OP_MUL_CONST, pk->c_betainv);
       }
-      pr.op(OP_STORE, 2 * s);
-      pr.pop();
-      for (uint32_t j = lo; j < hi; j++) {  // numerator: prod (v + beta*delta^j*omega^row + gamma)
-        pr.op(OP_PUSH_COL, COL(pk->sl_omega(), r0));
-        pr.push();
-        pr.op(OP_MUL_CONST, pk->c_bdelta + j);
-        pr.op(OP_ADD_COL, COL(colkind_slot_lag(pk->perm_cols[j]), r0));
-        pr.op(OP_ADD_CONST, pk->c_gamma);
-        if (j > lo) {
-          pr.op(OP_MUL);
-          pr.pop();
+      for (int side = 0; side < 2; side++) {  // 0: denominator (sigma columns), 1: numerator (identity-permutation columns)
+        for (uint32_t j = lo; j < hi; j++) {
+          // the stack holds the m values w, then (from the second factor on) the running product
+          pr.op(OP_PICK, j == lo ? m - 1 : m - (j - lo));
+          pr.push();
+          pr.op(OP_ADD_COL, COL(side == 0 ? pk->sl_sigma(j) : pk->sl_dxw(j), r0));
+          if (j > lo) {
+            pr.op(OP_MUL);
+            pr.pop();
+          }
         }
+        if (side == 1) {
+          pr.op(OP_NIP, m);
+          pr.cur -= m;
+        }
+        pr.op(OP_STORE, 2 * s + side);
+        pr.pop();
       }
-      pr.op(OP_STORE, 2 * s + 1);
-      pr.pop();
     }
     std::vector<Fr*> outs(2 * ns);
     for (uint32_t s = 0; s < ns; s++) outs[2 * s] = pk->frac + (size_t)s * n, outs[2 * s + 1] = pk->zp() + (size_t)s * n;
@@ -1144,6 +1213,7 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
   {
     Program& pr = pk->prog_lfrac;
     for (uint32_t l = 0; l < L; l++) {
+      pr.piece();
       pr.op(OP_PUSH_COL, COL(pk->sl_la(l), r0));
       pr.push();
       pr.op(OP_ADD_CONST, pk->c_beta);
@@ -1201,26 +1271,32 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
         pr.op(OP_ACC); pr.pop();
       }
       // l_active * (z_i(omega X) prod(v + beta sigma + gamma) - z_i(X) prod(v + beta delta^j X + gamma))
+      //   = beta^m * l_active * (z_i(omega X) prod(sigma_j + w_j) - z_i(X) prod(delta^j X + w_j)),  w_j = (v_j + gamma) / beta:
+      // the w_j stay on the stack for both products (one product per column instead of two), delta^j X is a key column,
+      // and beta^m goes into the term's power of y (h_term_beta_pow, upload_ypow)
       for (uint32_t s = 0; s < ns; s++) {
-        uint32_t lo = s * pk->chunk, hi = std::min(S, lo + pk->chunk);
+        const uint32_t lo = s * pk->chunk, hi = std::min(S, lo + pk->chunk), m = hi - lo;
+        for (uint32_t j = lo; j < hi; j++) {
+          pr.op(OP_PUSH_COL, COL(colkind_slot_ext(pk->perm_cols[j]), r0)); pr.push();
+          pr.op(OP_ADD_CONST, pk->c_gamma);
+          pr.op(OP_MUL_CONST, pk->c_betainv);
+        }
         pr.op(OP_PUSH_COL, COL(pk->se_zp(s), r1)); pr.push();
         for (uint32_t j = lo; j < hi; j++) {
-          pr.op(OP_PUSH_COL, COL(pk->se_sigma(j), r0)); pr.push();
-          pr.op(OP_MUL_CONST, pk->c_beta);
-          pr.op(OP_ADD_COL, COL(colkind_slot_ext(pk->perm_cols[j]), r0));
-          pr.op(OP_ADD_CONST, pk->c_gamma);
+          pr.op(OP_PICK, m - (j - lo)); pr.push();
+          pr.op(OP_ADD_COL, COL(pk->se_sigma(j), r0));
           pr.op(OP_MUL); pr.pop();
         }
         pr.op(OP_PUSH_COL, COL(pk->se_zp(s), r0)); pr.push();
         for (uint32_t j = lo; j < hi; j++) {
-          pr.op(OP_PUSH_HOT, 3); pr.push();
-          pr.op(OP_MUL_CONST, pk->c_bdelta + j);
-          pr.op(OP_ADD_COL, COL(colkind_slot_ext(pk->perm_cols[j]), r0));
-          pr.op(OP_ADD_CONST, pk->c_gamma);
+          pr.op(OP_PICK, 1 + m - (j - lo)); pr.push();
+          pr.op(OP_ADD_COL, COL(pk->se_dx(j), r0));
           pr.op(OP_MUL); pr.pop();
         }
         pr.op(OP_SUB); pr.pop();
+        pr.op(OP_NIP, m); pr.cur -= m;
         pr.op(OP_MUL_HOT, 2);
+        pr.next_beta = m;
         pr.op(OP_ACC); pr.pop();
       }
     }
@@ -1284,6 +1360,7 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
   KG_TRY(upload_program(ctx, pk, pk->prog_pfrac, false));
   KG_TRY(upload_program(ctx, pk, pk->prog_lfrac, false));
   pk->h_terms = finalize_limb_program(pk->prog_h);
+  pk->h_term_beta_pow = pk->prog_h.term_beta;
   KG_TRY(dalloc(ctx, pk, &pk->d_ypow, (size_t)std::max<uint32_t>(pk->h_terms, 1)));
   KG_TRY(upload_program(ctx, pk, pk->prog_h, true));
   if (getenv("AMDZK_DUMP_PROG")) {  // debugging aid: what the compiled h(X) program is made of
@@ -1645,14 +1722,10 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
   trace_fr("gamma", gamma);
   pk->consts[pk->c_beta] = beta;
   pk->consts[pk->c_gamma] = gamma;
-  {
-    Fr cur = beta, delta = fr_delta();
-    for (uint32_t j = 0; j < S; j++) {
-      pk->consts[pk->c_bdelta + j] = cur;
-      cur = mul(cur, delta);
-    }
-    ZK_TRY(h2d_staged(ctx, pk, pk->d_consts + pk->c_beta, &pk->consts[pk->c_beta], (size_t)(pk->consts.size() - pk->c_beta) * 32));
-  }
+  // the permutation factors are evaluated as beta (sigma + w) and beta (delta^j X + w) with w = (v + gamma) / beta
+  if (S && beta.is_zero()) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "create_proof: the challenge beta is zero (probability 2^-254): the factored permutation terms need 1 / beta");
+  pk->consts[pk->c_betainv] = inv(beta);
+  ZK_TRY(h2d_staged(ctx, pk, pk->d_consts + pk->c_beta, &pk->consts[pk->c_beta], (size_t)(pk->consts.size() - pk->c_beta) * 32));
   tick("  perm: challenges+consts");
   // 3. + 4. permutation grand products on M, lookup grand products on C (they depend on beta and gamma only, not on
   // each other). RNG order: the permutation sets' tails and blinds, then the lookups'.
@@ -2089,11 +2162,8 @@ int amdzk_quotient_eval_dev(amdzk_ctx* ctx, amdzk_pk* pk, const void* d_polys, s
   memcpy(pk->consts[pk->c_beta].l, beta, 32);
   memcpy(pk->consts[pk->c_gamma].l, gamma, 32);
   memcpy(pk->consts[pk->c_y].l, y, 32);
-  Fr cur = pk->consts[pk->c_beta], delta = fr_delta();
-  for (uint32_t j = 0; j < pk->S; j++) {
-    pk->consts[pk->c_bdelta + j] = cur;
-    cur = mul(cur, delta);
-  }
+  if (pk->S && pk->consts[pk->c_beta].is_zero()) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "quotient_eval: beta is zero");
+  pk->consts[pk->c_betainv] = inv(pk->consts[pk->c_beta]);
   ZK_TRY(quotient_pieces(ctx, pk));
   ZK_TRY(d2d(ctx, d_pieces_out, pk->hpieces, (size_t)pk->qdeg * pk->n * 32));
   ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));

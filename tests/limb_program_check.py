@@ -4,7 +4,7 @@ documents for each function, and asserts every precondition — the safety net b
 (prover.hip finalize_limb_program) that places the weak reductions."""
 
 OPS = dict(END=0, PUSH_COL=1, PUSH_CONST=2, ADD=3, SUB=4, MUL=5, NEG=6, MUL_CONST=7, ADD_CONST=8, MUL_COL=9, ADD_COL=10, SUB_COL=11, ACC=12,
-           STORE=13, SQR=14, PUSH_HOT=15, MUL_HOT=16, REDUCE=17, SUB_BIG=18, NEG_BIG=19, WACC=20, WFLUSH=21)
+           STORE=13, SQR=14, PUSH_HOT=15, MUL_HOT=16, REDUCE=17, SUB_BIG=18, NEG_BIG=19, WACC=20, WFLUSH=21, PICK=22, NIP=23)
 NAME = {v: k for k, v in OPS.items()}
 MUL_RANGE = 169.0      # f29_mul / f29_sqr / f29_mul2: a*b (+ c*d) < 169 p^2
 VALUE_RANGE = 169.0    # a normalised value must stay below 2^261 = 169.3 p
@@ -76,6 +76,14 @@ def check(words):
                 g = 2.0
             assert g + 1.0 < VALUE_RANGE, where              # + h (canonical), then f29_reduce_weak
             wide, uncarried = 0.0, 0
+        elif op == "PICK":                                   # copy of the entry `arg` below the top
+            k = w & 0xFFFFFF
+            assert k < len(st), where
+            st.append(st[-1 - k])
+        elif op == "NIP":                                    # the `arg` entries below the top are discarded
+            k = w & 0xFFFFFF
+            assert k < len(st), where
+            del st[len(st) - 1 - k:len(st) - 1]
         elif op == "STORE":                                  # f29_pack_canonical: below 2p
             assert st.pop() < 2.0, where
         elif op == "END":

@@ -346,6 +346,10 @@ def test_h_program_of_the_metric_shape_respects_every_bound(ctx, pkg, oracle):
     nsets = (118 + c.desc["cs_degree"] - 3) // (c.desc["cs_degree"] - 2)
     assert nterms == 93 + (2 + nsets - 1 + nsets) + 5 * 24
     assert names.count("WFLUSH") == 4 and "MUL_HOT" not in names  # l_0, l_last, l_active groups + the gates
-    assert depth <= 4
+    # stack: the set's two shared values w_j, the two running products and one copy in flight (round 3: the factored
+    # permutation terms); 4 products per 2-column set instead of 8 multiplications by constants and running products
+    assert depth <= 5
+    assert names.count("PICK") == 2 * 118 and names.count("NIP") == nsets
+    assert names.count("MUL_CONST") + names.count("MUL") + names.count("MUL_COL") + names.count("SQR") <= 812 - 118 + 8
     pk.free()
     params.free()

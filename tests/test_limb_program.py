@@ -132,3 +132,31 @@ def test_checker_rejects_an_unreduced_program():
     bad = [W("PUSH_COL", 0)] + [W("ADD_COL", 1)] * 14 + [W("SQR"), W("STORE", 0)]
     with pytest.raises(AssertionError):
         LC.check(bad)
+
+
+def test_shared_values_are_picked_from_the_stack(pkg):
+    """The factored permutation term of a 2-column set, l_active * (z(wX) (s0 + w0)(s1 + w1) - z(X) (d0 + w0)(d1 + w1)) with
+    w_j = (v_j + gamma) / beta computed once and copied (OP_PICK) into both products, then dropped from under the result
+    (OP_NIP): the pass keeps the structure, tracks the copies' bounds, and the closing `* hot 2` still leaves the term."""
+    v0, v1, s0, s1, d0, d1, z = 1, 2, 3, 4, 5, 6, 7
+    prog = [W("PUSH_COL", v0), W("ADD_CONST", 1), W("MUL_CONST", 2),
+            W("PUSH_COL", v1), W("ADD_CONST", 1), W("MUL_CONST", 2),
+            W("PUSH_COL", z),
+            W("PICK", 2), W("ADD_COL", s0), W("MUL"),
+            W("PICK", 1), W("ADD_COL", s1), W("MUL"),
+            W("PUSH_COL", z),
+            W("PICK", 3), W("ADD_COL", d0), W("MUL"),
+            W("PICK", 2), W("ADD_COL", d1), W("MUL"),
+            W("SUB"), W("NIP", 2), W("MUL_HOT", 2), W("ACC")]
+    out, depth = finalize(pkg, prog)
+    o = ops(out)
+    assert o.count("PICK") == 4 and o.count("NIP") == 1 and "MUL_HOT" not in o and o[-2:] == ["WACC", "WFLUSH"]
+    assert out[-1] & 7 == 2                       # the group of l_active
+    assert o.count("MUL_CONST") == 2 and o.count("MUL") == 4   # 6 products for 2 columns (8 before the factoring)
+    d, nred, nterms = LC.check(out)
+    assert d == 5 and nterms == 1 and depth >= 5
+
+
+def test_checker_rejects_a_pick_below_the_stack():
+    with pytest.raises(AssertionError):
+        LC.check([W("PUSH_COL", 1), W("PICK", 1), W("ADD"), W("WACC", 0), W("WFLUSH", 4 | 16)])
