@@ -167,7 +167,7 @@ class GpuProver:
         # (serial keys: the proofs already fill the chip between them; spreading each over three streams as well costs
         # 1-2 % of the rate, profiles/r03b_*); the single-proof latency is measured with a default (lanes) key.
         self.serial_keys = P >= 4 and os.environ.get("AMDZK_BENCH_LANES_KEYS") != "1"
-        flags = self.plonk.KEYGEN_SERIAL if self.serial_keys else 0
+        flags = self.plonk.KEYGEN_SERIAL if self.serial_keys else None  # None: the library's default (lanes, unless AMDZK_SERIAL=1)
         self.pks = [self.plonk.ProvingKey(cx, self.params, self.desc, fixed_host, c.assembly.mapping, tr, flags=flags) for cx in self.ctxs]
         self.fixed_host, self.tr = fixed_host, tr
         self._lat_keys = {}
@@ -198,7 +198,7 @@ class GpuProver:
     def latency(self, seed, serial, reps=3):
         """One proof alone on the GPU with a key of the given mode — default: the proof's independent work on three streams
         (lanes); serial: one stream, as in rounds 1-2 — `reps` times after one untimed proof: (median ms, the last proof)."""
-        want_flags = self.plonk.KEYGEN_SERIAL if serial else 0
+        want_flags = self.plonk.KEYGEN_SERIAL if serial else None  # None: the library's default (lanes, unless AMDZK_SERIAL=1)
         if bool(serial) == bool(self.serial_keys):
             pk, own = self.pks[0], False
         else:
