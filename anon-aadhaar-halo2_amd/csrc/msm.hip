@@ -299,8 +299,9 @@ struct AccArgs {
 // buckets they belong to, and emits one partial sum per bucket segment it crosses (slot
 // off_out[b] + (t - off_in[b]/T)). Every lane of a wavefront performs the same number of additions,
 // so skewed witness columns (thousands of tiny buckets next to a few huge ones) no longer leave most
-// lanes idle behind the longest task. FIRST is the hot kernel of the whole prover: a mixed addition is
-// 10 in-place-accumulating products (fq29_mul) on a window-table point (packed canonical, radix 2^261).
+// lanes idle behind the longest task. FIRST is the hot kernel of the whole prover: a mixed addition (madd-2008-s on
+// 29-bit limbs) is 6 products, 2 squares and one two-product reduction (y3 = r (q - x3) - y1 ppp, f29_mul2) — 1,539
+// multiply-adds — on a window-table point (packed canonical, radix 2^261).
 template <bool FIRST>
 __global__ __launch_bounds__(MSM_THREADS) void msm_accum_seg_kernel(AccArgs a) {
   const uint32_t col = blockIdx.y;
