@@ -362,6 +362,26 @@ __device__ __forceinline__ G1X29 wave_sum29(G1X29 v) {
   for (int m = 32; m >= 1; m >>= 1) v = x29_add(v, shfl_xor_x29(v, m));
   return v;
 }
+__device__ __forceinline__ G1X29 shfl_down_x29(const G1X29& v, int d) {
+  G1X29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    r.x.l[i] = __shfl_down(v.x.l[i], d, 64);
+    r.y.l[i] = __shfl_down(v.y.l[i], d, 64);
+    r.zz.l[i] = __shfl_down(v.zz.l[i], d, 64);
+    r.zzz.l[i] = __shfl_down(v.zzz.l[i], d, 64);
+  }
+  return r;
+}
+// Lane l ends with the sum of the inputs of lanes l .. 63 (six shuffle rounds).
+__device__ __forceinline__ G1X29 wave_suffix29(G1X29 v, uint32_t lane) {
+#pragma unroll 1
+  for (int d = 1; d < 64; d <<= 1) {
+    const G1X29 o = shfl_down_x29(v, d);
+    v = x29_add(v, lane + d < 64 ? o : G1X29::inf());
+  }
+  return v;
+}
 // The 32-bit flavour, for the start-up-only group FFT below.
 __device__ __forceinline__ Fq shfl_xor_fq(const Fq& v, int m) {
   Fq r;
@@ -455,40 +475,56 @@ __device__ __forceinline__ G1X x_mul_small(const G1X& p, uint32_t k, int nbits) 
 
 // out[col] = sum_r r*cols[r] + sum_g (64g+1)*rows[g]
 //          = sum_r r*cols[r] + 64 * (sum_g g*rows[g]) + sum_g rows[g].
-// Three independent reductions on separate wavefronts (W = ceil(G/64) waves for each row sum, one for
-// the columns), so the dependent chain is a 6..9-bit double-and-add, one shuffle tree, six doublings
-// and a handful of additions — the kernel is pure latency (one workgroup per column). The result leaves
-// in the packed radix-2^256 XYZZ form (x29_to_r256): the only radix conversion of the whole MSM.
-__global__ __launch_bounds__(576) void msm_fold_kernel(const G1X29* rows, const G1X29* cols, uint32_t nb, G1X* out, int split) {
-  __shared__ G1X29 part[17];
+// A weighted sum sum_l l * v_l over the 64 lanes of a wavefront is the sum of the suffix sums S_1 .. S_63 (S_l = v_l + ... +
+// v_63): six shuffle rounds for the suffixes, six for their sum — 12 dependent point additions where the per-lane 6-bit
+// double-and-add followed by a shuffle tree took 18 — and S_0, the plain sum, comes with it (round 3). One wavefront per 64
+// row sums (W = ceil(G / 64) of them; g = 64 w + l gives sum_g g v_g = sum_w (A_w + 64 w B_w), A_w the wavefront's
+// weighted sum and B_w its plain sum) and one for the 64 column sums; lane 0 of the first wavefront combines them by
+// Horner (6 doublings per factor 64). The kernel is pure latency, one workgroup per column, at the end of every
+// commitment batch. The result leaves in the packed radix-2^256 XYZZ form (x29_to_r256): the only radix conversion of
+// the whole MSM.
+__global__ __launch_bounds__(576) void msm_fold_kernel(const G1X29* rows, const G1X29* cols, uint32_t nb, G1X* out) {
+  __shared__ G1X29 partA[8], partB[8], partC;
   const uint32_t col = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const uint32_t G = nb >> 6, W = (G + 63) >> 6;
-  const int gbits = 32 - __clz(G > 1 ? G - 1 : 1);
-  if (wv < W) {  // sum_g g*rows[g]  (and, when not split, sum_g rows[g] as well)
-    const uint32_t g = wv * 64 + lane;
-    G1X29 v = g < G ? ld_x29(rows + (size_t)col * G + g) : G1X29::inf();
-    G1X29 s = wave_sum29(x29_mul_small(v, g, gbits));
-    if (lane == 0) part[wv] = s;
-    if (!split) {
-      G1X29 u = wave_sum29(v);
-      if (lane == 0) part[8 + wv] = u;
+  if (wv <= W) {
+    G1X29 v;
+    if (wv < W) {
+      const uint32_t g = wv * 64 + lane;
+      v = g < G ? ld_x29(rows + (size_t)col * G + g) : G1X29::inf();
+    } else {
+      v = ld_x29(cols + (size_t)col * 64 + lane);
     }
-  } else if (split && wv < 2 * W) {  // sum_g rows[g]
-    const uint32_t g = (wv - W) * 64 + lane;
-    G1X29 u = wave_sum29(g < G ? ld_x29(rows + (size_t)col * G + g) : G1X29::inf());
-    if (lane == 0) part[8 + wv - W] = u;
-  } else {  // sum_r r*cols[r]
-    G1X29 c = wave_sum29(x29_mul_small(ld_x29(cols + (size_t)col * 64 + lane), lane, 6));
-    if (lane == 0) part[16] = c;
+    const G1X29 suf = wave_suffix29(v, lane);
+    if (lane == 0 && wv < W) partB[wv] = suf;
+    const G1X29 wsum = wave_sum29(lane == 0 ? G1X29::inf() : suf);
+    if (lane == 0) {
+      if (wv < W) partA[wv] = wsum;
+      else partC = wsum;
+    }
   }
   __syncthreads();
   if (t == 0) {
-    G1X29 acc = part[0];
-    for (uint32_t i = 1; i < W; i++) acc = x29_add(acc, part[i]);
+    G1X29 sum_b = partB[0], acc = partA[0];
+    if (W > 1) {
+      // Y = sum_w w B_w = the sum of the suffix sums of B over w = 1 .. W - 1; then acc = 64 Y + sum_w A_w
+      G1X29 suf = partB[W - 1], y = partB[W - 1];
+      for (uint32_t w = W - 2; w >= 1; w--) {
+        suf = x29_add(suf, partB[w]);
+        y = x29_add(y, suf);
+      }
+#pragma unroll 1
+      for (int i = 0; i < 6; i++) y = x29_dbl(y);
+      for (uint32_t w = 1; w < W; w++) {
+        acc = x29_add(acc, partA[w]);
+        sum_b = x29_add(sum_b, partB[w]);
+      }
+      acc = x29_add(acc, y);
+    }
 #pragma unroll 1
     for (int i = 0; i < 6; i++) acc = x29_dbl(acc);
-    for (uint32_t i = 0; i < W; i++) acc = x29_add(acc, part[8 + i]);
-    st_x(out + col, x29_to_r256(x29_add(acc, part[16])));
+    acc = x29_add(acc, sum_b);
+    st_x(out + col, x29_to_r256(x29_add(acc, partC)));
   }
 }
 
@@ -1049,10 +1085,8 @@ static int msm_group(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const MsmG
             g.cap[MSM_NLEV], dense);
   ZK_LAUNCH(ctx, "msm_rowcol", msm_rowcol_kernel, dim3((unsigned)(1 + (g.G + 63) / 64), (unsigned)ncols), dim3(64 * ROWCOL_WAVES), 0, dense, nb, rows,
             cols);
-  const unsigned fold_w = (unsigned)((g.G + 63) / 64);  // 1, 2, 4 or 8 (c <= 16)
-  const int fold_split = fold_w <= 4;                    // at most 9 wavefronts per workgroup either way (launch bound 576)
-  ZK_LAUNCH(ctx, "msm_fold", msm_fold_kernel, dim3((unsigned)ncols), dim3(64 * ((fold_split ? 2 : 1) * fold_w + 1)), 0, rows, cols, nb, outp,
-            fold_split);
+  const unsigned fold_w = (unsigned)((g.G + 63) / 64);  // 1, 2, 4 or 8 (c <= 16): at most 9 wavefronts per workgroup (launch bound 576)
+  ZK_LAUNCH(ctx, "msm_fold", msm_fold_kernel, dim3((unsigned)ncols), dim3(64 * (fold_w + 1)), 0, rows, cols, nb, outp);
   return AMDZK_OK;
 }
 
