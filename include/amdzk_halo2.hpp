@@ -54,6 +54,9 @@ class Context {
   void check(int rc) const {
     if (rc != AMDZK_OK) throw Error(rc, amdzk_last_error(h_));
   }
+  // amdzk_set_host_wait: true = this context's calls sleep while they wait for the device (hosts with more proofs in
+  // flight than cores to spare), false = they spin (the default: lowest latency)
+  void set_blocking_waits(bool block) const { check(amdzk_set_host_wait(h_, block ? AMDZK_WAIT_BLOCK : AMDZK_WAIT_SPIN)); }
 
  private:
   amdzk_ctx* h_ = nullptr;
@@ -570,8 +573,10 @@ class ParamsKZG {
 // plonk::keygen_vk + keygen_pk: fixed[c] = the 2^k Lagrange values of fixed column c (selectors included).
 class ProvingKey {
  public:
+  // flags: AMDZK_KEYGEN_* of include/amdzk.h or'ed together; kEnvDefaults = amdzk_keygen (the modes from the environment)
+  static constexpr uint32_t kEnvDefaults = 0xffffffffu;
   ProvingKey(const Context& ctx, const ParamsKZG& params, const ConstraintSystem& cs, const std::vector<std::vector<Fr>>& fixed,
-             const Assembly& assembly, const Fr& transcript_repr)
+             const Assembly& assembly, const Fr& transcript_repr, uint32_t flags = kEnvDefaults)
       : ctx_(ctx), num_fixed_(cs.num_fixed), num_perm_(cs.permutation_columns.size()), num_advice_(cs.num_advice), k_(params.k()) {
     const size_t n = (size_t)1 << k_;
     if (fixed.size() != cs.num_fixed) throw Error(AMDZK_E_INVALID, "keygen: fixed column count");
@@ -582,8 +587,10 @@ class ProvingKey {
       std::copy(fixed[c].begin(), fixed[c].end(), flat.begin() + c * n);
     }
     CircuitData cd(cs, k_);
-    ctx_.check(amdzk_keygen(ctx_.get(), params.handle(), &cd.c, flat.empty() ? nullptr : (const uint64_t*)flat.data(),
-                            num_perm_ ? assembly.mapping() : nullptr, transcript_repr.l, &h_));
+    const uint64_t* fx = flat.empty() ? nullptr : (const uint64_t*)flat.data();
+    const uint32_t* mp = num_perm_ ? assembly.mapping() : nullptr;
+    if (flags == kEnvDefaults) ctx_.check(amdzk_keygen(ctx_.get(), params.handle(), &cd.c, fx, mp, transcript_repr.l, &h_));
+    else ctx_.check(amdzk_keygen_ex(ctx_.get(), params.handle(), &cd.c, fx, mp, transcript_repr.l, flags, &h_));
   }
   ~ProvingKey() {
     if (h_) amdzk_pk_free(ctx_.get(), h_);

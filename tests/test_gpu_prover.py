@@ -147,6 +147,25 @@ def test_high_degree_gate_bytes_equal_oracle(ctx, pkg, plonk, oracle, power, fla
     d_adv.free(); pk.free(); params.free()
 
 
+def test_host_wait_modes_give_the_same_bytes(ctx, pkg, plonk, oracle):
+    """amdzk_set_host_wait: spinning (hipStreamSynchronize) and blocking (polled completion event) waits are the same
+    proof — lanes and serial keys, and the mode can be switched between proofs on one context."""
+    c = circuits.lookup_circuit(plonk, 6, seed=5)
+    opk = PR.keygen(c.desc, c.fixed, c.assembly.mapping, TAU, transcript_repr=123456789)
+    want = PR.create_proof(opk, c.instances, c.advice, seed=41)
+    try:
+        for flags in (0, plonk.KEYGEN_SERIAL):
+            params, pk, d_adv, inst = setup(ctx, pkg, plonk, oracle, c, flags=flags)
+            for block in (True, False, True):
+                ctx.set_host_wait(block)
+                assert plonk.create_proof(ctx, pk, inst, d_adv, seed=41) == want
+            d_adv.free(); pk.free(); params.free()
+    finally:
+        ctx.set_host_wait(False)
+    with pytest.raises(Exception):
+        ctx._chk(ctx.L.amdzk_set_host_wait(ctx.h, 7))
+
+
 def test_keygen_ex_rejects_unknown_flags(ctx, pkg, plonk, oracle):
     c = circuits.square_circuit(plonk, 4, signal=5)
     with pytest.raises(Exception):
