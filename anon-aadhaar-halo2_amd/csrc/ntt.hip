@@ -100,10 +100,19 @@ __device__ __forceinline__ Fr tw_lookup(const Fr* tw, uint32_t e, uint32_t log_n
 // below 2; every third round the sums are brought back below 2 with f29_reduce_weak (~30 instructions), so
 // no element exceeds 16.8 and every subtrahend stays below 9 (the range f29_sub10 covers). Elements are
 // packed to canonical 32-byte values only when they leave the tile.
-// Element e of the tile sits at slot e + (e >> 5): one empty slot per 32 elements. The radix-4 blocks read and write
-// runs of 2^(a-1) * C consecutive elements that are 4 runs apart; in the last blocks a run is 4-16 elements, and without
-// the skew the runs of a half-wavefront would all start on the same banks (8-way conflicts at run length 4).
-__device__ __forceinline__ uint32_t tile_slot(uint32_t e) { return e + (e >> 5); }
+// Element e of the tile sits at slot e ^ g((e >> 5) & 3), g(t) = t replicated over the low five bits. The radix-4 blocks
+// read and write, per element of a group, the elements whose index is the lane number with two zero bits inserted at
+// bit p = (a - 1) + log C; for p < 5 the 32 lanes of a half-wavefront would otherwise reach only 8 of the 32 banks (the
+// limb stride, 9 words, is odd, so banks follow the slot number). XOR-ing a copy of index bits 5-6 — exactly the lane bits
+// the insertion pushed out of the low five — into every bit pair fills the two zero bits again, whatever p is, and is a
+// bijection on the tile (identity for tiles below 128 elements); contiguous accesses (the load phase) stay conflict-free.
+// Measured (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, tools/ntt_microbench.py): 34 % -> 26 % of the LDS-active cycles in
+// the last step, an unchanged 45 % in the first (whose conflicts are the bit-reversed read of its store phase), and
+// 0.6 % of the kernels' time: the transform does not wait for LDS (SQ_WAIT_INST_LDS is 4 % of its wave cycles).
+__device__ __forceinline__ uint32_t tile_slot(uint32_t e) {
+  const uint32_t t = (e >> 5) & 3u;
+  return e ^ (t | (t << 2) | ((t & 1u) << 4));
+}
 __device__ __forceinline__ Fr29 lds_ld(const uint32_t* L, uint32_t e) {
   Fr29 r;
   const uint32_t s = tile_slot(e) * 9;
@@ -138,7 +147,7 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
   const uint32_t C = 1u << a.log_c;
   const uint32_t rows = 1u << a.s;
   const uint32_t tile = rows << a.log_c;
-  uint32_t* TW = L + (size_t)(tile + (tile >> 5) + 1) * 9;  // rows/2 sub-transform twiddles omega_{n_p}^i (radix 2^261), as limbs
+  uint32_t* TW = L + (size_t)tile * 9;  // rows/2 sub-transform twiddles omega_{n_p}^i (radix 2^261), as limbs
   const uint32_t tile_id = blockIdx.x;
   const Fr* in = a.in + (size_t)blockIdx.y * a.in_col_stride + (size_t)blockIdx.z * a.in_z_stride;
   Fr* out = a.out + (size_t)blockIdx.y * a.out_col_stride + (size_t)blockIdx.z * a.out_z_stride;
@@ -457,7 +466,7 @@ int zk_ntt_ex(amdzk_ctx* ctx, const Fr* d_in, size_t in_stride, Fr* d_out, size_
     threads = threads < 64 ? 64 : threads > (uint32_t)NTT_THREADS ? (uint32_t)NTT_THREADS : threads;
     dim3 grid((uint32_t)(n >> tile_elems_log), (uint32_t)ncols, nz), block(threads);
     const size_t tile_elems = (size_t)1 << tile_elems_log;
-    size_t shmem = (tile_elems + (tile_elems >> 5) + 1 + ((size_t)1 << a.s) / 2 + 1) * 9 * sizeof(uint32_t);  // limbs + skew slots, see ntt_step_kernel
+    size_t shmem = (tile_elems + ((size_t)1 << a.s) / 2 + 1) * 9 * sizeof(uint32_t);  // limbs, see ntt_step_kernel
     if (last) {
       if (shmem > 65536) ZK_HIP(ctx, hipFuncSetAttribute((const void*)ntt_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
       ZK_LAUNCH(ctx, "ntt_step_last", ntt_step_kernel<true>, grid, block, shmem, a);
