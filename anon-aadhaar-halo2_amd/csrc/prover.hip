@@ -1750,6 +1750,12 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     LN_TRY(C, zk_mul_elem(C, pk->zl(), pk->frac2, (size_t)L * n));
     LN_TRY(C, zk_running_product(C, pk->zl(), L, n, n, false, 0, pk->scan_tmp2));
     ZK_TRY(blind_rows(C, pk->zl(), L, n - bf, bf, tail_l));
+    // ... and their commitment, enqueued BEFORE the permutation chain: the lookup chain is the shorter one, so its
+    // level-1 kernel runs while M is still in fractions, inversion and scans rather than beside M's own level-1 kernel.
+    // (Measured: 18.8-19.3 ms per proof either way — what one lane gains the other loses; kept for the simpler order.)
+    if (serial || !gate_l1) ZK_TRY(transforms_on_B(C, (size_t)A + I + 2 * L + ns, L));
+    ZK_TRY(commit_begin(C, AMDZK_BASIS_G_LAGRANGE, pk->zl(), L, cm_zl));
+    if (!serial && gate_l1) ZK_TRY(transforms_on_B(C, (size_t)A + I + 2 * L + ns, L, true));
   }
   if (ns) {
     ZK_TRY(run_program(ctx, pk, pk->prog_pfrac, false, pk->d_outs_pfrac, nullptr, "expr_perm_fractions"));
@@ -1762,11 +1768,6 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     ZK_TRY(blind_rows(M, pk->zp(), ns, n - bf, bf, tail_p));
     if (serial || !gate_l1) ZK_TRY(transforms_on_B(M, (size_t)A + I + 2 * L, ns));
     ZK_TRY(commit_begin(M, AMDZK_BASIS_G_LAGRANGE, pk->zp(), ns, cm_zp));
-  }
-  if (L) {
-    if (serial || !gate_l1) ZK_TRY(transforms_on_B(C, (size_t)A + I + 2 * L + ns, L));
-    ZK_TRY(commit_begin(C, AMDZK_BASIS_G_LAGRANGE, pk->zl(), L, cm_zl));
-    if (!serial && gate_l1) ZK_TRY(transforms_on_B(C, (size_t)A + I + 2 * L + ns, L, true));
   }
   if (ns && !serial && gate_l1) ZK_TRY(transforms_on_B(M, (size_t)A + I + 2 * L, ns, true));
   ZK_TRY(commit_end(cm_zp));
