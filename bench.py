@@ -74,7 +74,7 @@ def parse_args(argv=None):
                     help="confine this rank to the first N cores of its affinity mask (sched_setaffinity before any GPU call); 0 = leave it alone")
     ap.add_argument("--host-wait", default="auto", choices=("auto", "spin", "block"),
                     help="how the per-proof driver threads wait for the GPU during the timed steps: spin (hipStreamSynchronize), block "
-                         "(poll a completion event with 50-us sleeps), auto = block with 4 or more proofs in flight: same rate on 16 cores for a sixth of "
+                         "(poll a completion event with 50-us sleeps), auto = block with 4 or more proofs in flight or more than one rank: same rate on 16 cores for a sixth of "
                          "the CPU time, and 73 instead of 63 proofs/s on 2 cores (profiles/r03e_host_wait_and_cu_mask.txt)")
     ap.add_argument("--no-k22", action="store_true", help="skip BASELINE config 5 (2^22-point MSM and NTT, config.k22_stress) and the CPU kernel baselines")
     return ap.parse_args(argv)
@@ -401,7 +401,7 @@ def run_rank(args):
             prover.prove(cx, (cx + r) % nw, 1000 * rank + 500000 + r * P + cx)
 
     # host waits: with more proofs in flight than cores to spare the driver threads sleep instead of spinning
-    block_waits = args.host_wait == "block" or (args.host_wait == "auto" and P >= 4)
+    block_waits = args.host_wait == "block" or (args.host_wait == "auto" and (P >= 4 or world > 1))
     if not stub:
         for cx in prover.ctxs:
             cx.set_host_wait(block_waits)
