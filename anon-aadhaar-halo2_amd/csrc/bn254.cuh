@@ -364,8 +364,9 @@ ZK_HD Fp<P> inv(const Fp<P>& a) {
 // a^-1 by the binary extended Euclidean algorithm on 8 x u32 limbs, host or device; inv_gcd(0) = 0. Data-dependent
 // control flow: on the device this is for ONE lane working while its workgroup waits (batch inversion: one inversion per
 // workgroup) — ~750 shift/subtract steps of ~40 dependent instructions against the Fermat chain's 380 products of ~206.
+// inv_gcd_plain: the inverse of the 256-bit INTEGER a modulo p, as an integer (no Montgomery factor in or out).
 template <class P>
-ZK_HD Fp<P> inv_gcd(const Fp<P>& a) {
+ZK_HD Fp<P> inv_gcd_plain(const Fp<P>& a) {
   if (a.is_zero()) return a;
   uint32_t u[8], v[8], x1[8], x2[8], p[8];
 #pragma unroll
@@ -430,8 +431,12 @@ ZK_HD Fp<P> inv_gcd(const Fp<P>& a) {
   const bool first = is_one(u);
 #pragma unroll
   for (int i = 0; i < 8; i++) o.l[i] = first ? x1[i] : x2[i];
-  // the inverse of the Montgomery representative a R is a^-1 R^-1: two products by R^2 make it a^-1 R
-  return mul(mul(o, Fp<P>::r2()), Fp<P>::r2());
+  return o;
+}
+// the inverse of the Montgomery representative a R is a^-1 R^-1 as an integer: two products by R^2 make it a^-1 R
+template <class P>
+ZK_HD Fp<P> inv_gcd(const Fp<P>& a) {
+  return mul(mul(inv_gcd_plain(a), Fp<P>::r2()), Fp<P>::r2());
 }
 
 using Fr = Fp<FrP>;
