@@ -11,10 +11,11 @@ def shard_indices(num_proofs, rank, world):
     return list(range(rank, num_proofs, world))
 
 
-def gather_proofs(local_proofs, num_proofs, device="cpu"):
+def gather_proofs(local_proofs, num_proofs, device="cpu", force=False):
     """all_gather the ranks' proofs; returns the list of all proofs in index order on every rank.
-    local_proofs: this rank's proofs in the order of shard_indices()."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    local_proofs: this rank's proofs in the order of shard_indices(). force: run the collectives even in a one-rank
+    group (bench.py's AMDZK_BENCH_DIST_SELF rehearsal)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         assert len(local_proofs) == num_proofs
         return list(local_proofs)
     world, rank = dist.get_world_size(), dist.get_rank()

@@ -350,7 +350,16 @@ def run_rank(args):
             local_rank = int(os.environ["AMDZK_BENCH_FORCE_DEVICE"])
         torch.cuda.set_device(local_rank)
     coll_dev = "cuda" if backend == "nccl" else "cpu"
-    if world > 1:
+    # AMDZK_BENCH_DIST_SELF=1 (rehearsal on a one-GPU box, never set by the driver): a ONE-rank process group is made anyway
+    # and every collective of the N > 1 path — barrier, the max-over-ranks all_reduce, the all_gather of the proofs — runs
+    # on it, i.e. on RCCL with device tensors, which the gloo rehearsals of several ranks on one device cannot exercise.
+    dist_on = world > 1 or os.environ.get("AMDZK_BENCH_DIST_SELF") == "1"
+    if dist_on and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if dist_on:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -383,11 +392,11 @@ def run_rank(args):
 
     def barrier():
         prover.sync()
-        if world > 1:
+        if dist_on:
             dist.barrier()
 
     def max_over_ranks(dt):
-        if world == 1:
+        if not dist_on:
             return dt
         t = torch.tensor([dt], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -422,14 +431,14 @@ def run_rank(args):
             proofs = pr
     dt, host_cpu_s = sorted(regions)[len(regions) // 2]
     gathered_ok = None
-    if world > 1:
+    if dist_on:
         # the one exchange step: every rank's proofs (equal length) gathered on all ranks (RCCL all_gather)
         if stub:
             import __graft_entry__ as ge
             batch_mod = ge.load_package().batch
         else:
             batch_mod = prover.pkg.batch
-        gathered = batch_mod.gather_proofs(proofs, world * steps, device=coll_dev)
+        gathered = batch_mod.gather_proofs(proofs, world * steps, device=coll_dev, force=True)
         gathered_ok = len(gathered) == world * steps and all(len(p) == len(proofs[0]) for p in gathered) and \
             all(gathered[s * world + rank] == proofs[s] for s in range(steps))
         if not gathered_ok:
@@ -518,7 +527,7 @@ def run_rank(args):
                            "setup_s_excluded": round(prover.setup_s, 1)},
                 "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     prover.close()
