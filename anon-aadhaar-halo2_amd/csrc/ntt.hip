@@ -36,7 +36,9 @@ struct NttPassArgs {
   Fr* out;
   size_t in_col_stride;   // elements between consecutive columns (batch)
   size_t out_col_stride;
-  const Fr* tw;           // omega^i, i < n/2, each stored as omega^i * 2^261 (packed canonical): see fp29.cuh "mixed radix"
+  const Fr* tw;           // omega^i, each stored as omega^i * 2^261 (packed canonical): see fp29.cuh "mixed radix"; i < n (tw_full)
+                          // or i < n/2 (the second half is the negation of the first)
+  uint32_t tw_full;
   uint32_t log_n;
   uint32_t s;             // log2 of this step's sub-transform length n_p
   uint32_t log_c;         // log2 of C (tile = 2^s x C elements)
@@ -86,8 +88,11 @@ __device__ __forceinline__ void st_fr(Fr* p, const Fr& v) {
   q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
-// omega^e for e in [0, n): table holds the first half, the second half is its negation.
-__device__ __forceinline__ Fr tw_lookup(const Fr* tw, uint32_t e, uint32_t log_n) {
+// omega^e for e in [0, n). Domains up to 2^18 keep the whole table (8 MiB at most: the inter-step multiplier is then one
+// load); larger ones the first half, the second half being its negation (a 9-limb subtraction and a select per element).
+constexpr uint32_t TW_FULL_MAX_LOG_N = 18;
+__device__ __forceinline__ Fr tw_lookup(const Fr* tw, uint32_t e, uint32_t log_n, uint32_t full) {
+  if (full) return ld_fr(tw + e);  // (wave-uniform: a kernel argument)
   uint32_t half = 1u << (log_n - 1);
   Fr w = ld_fr(tw + (e & (half - 1)));
   return (e & half) ? neg(w) : w;
@@ -137,6 +142,9 @@ __device__ __forceinline__ void tw_st(uint32_t* T, uint32_t i, const Fr29& v) {
   for (int k = 0; k < 9; k++) T[i * 9 + k] = v.l[k];
 }
 __device__ __forceinline__ Fr pack_out(const Fr29& v_below_2p) { return f29_pack_canonical<FrP>(v_below_2p); }
+// between two steps (the workspace only the next step reads): the value as it is, below 2p < 2^255 — the next step's
+// bounds start from "below 2p" anyway, and the subtraction and select of the canonical form are ~45 instructions
+__device__ __forceinline__ Fr pack_between(const Fr29& v_below_2p) { return f29_pack_raw<FrP>(v_below_2p); }
 
 template <bool LAST>
 __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
@@ -221,9 +229,10 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
   // An odd number of rounds starts with a single round. The last block (a = 1) multiplies by ONE constant only: its
   // round-1 twiddles are omega^0 (skipped) and omega_4, round 0 has none — 1 product where the round-by-round code
   // spent 4. Bounds in units of p: every element enters a block below 4 (2 at the start); sums of the first round are
-  // below 8 (a valid subtrahend of f29_sub10*), twiddle products below 2, so the block leaves below 1.0002 (x0: the
-  // sum of sums, weakly reduced), 2, 4, 2 — and the last block, which has differences without a product behind them,
-  // below 18, 16, 24: all inside the range of the product / weak reduction every element leaves the tile through.
+  // below 8 (a valid subtrahend of f29_sub10*) and stay lazy, twiddle products below 2, so the block leaves below 1.0003
+  // (x0: the sum of sums, weakly reduced), 2, 4, 2 — and the last block, which has differences without a product behind
+  // them, below 18, 16, 24: all inside the range of the product / weak reduction every element leaves the tile through.
+  // The arithmetic of a block is fp29.cuh's f29_dif4 / f29_dif4_last (checked on the host with the bounds as hard failures).
   int st = (int)a.s - 1;
   if (a.s & 1) {  // single round, half-length 2^(s-1): butterfly (x, x + h), twiddle omega_{n_p}^x
     const uint32_t h = 1u << st;
@@ -245,27 +254,13 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
       const uint32_t c = q & (C - 1), gq = q >> a.log_c;
       const uint32_t lo = gq & (hq - 1), hi = gq >> (st - 1);
       const uint32_t e0 = ((((hi << 2) << (st - 1)) | lo) << a.log_c) + c, e1 = e0 + estep, e2 = e1 + estep, e3 = e2 + estep;
-      const Fr29 u0 = lds_ld(L, e0), u1 = lds_ld(L, e1), u2 = lds_ld(L, e2), u3 = lds_ld(L, e3);
-      const Fr29 s0 = f29_add(u0, u2), s1 = f29_add(u1, u3);
-      Fr29 y1, y2, y3;
-      if (last_block) {
-        const Fr29 d0 = f29_sub10(u0, u2);                                                       // omega^0
-        const Fr29 d1 = f29_mul(f29_sub10_lazy(u1, u3), tw_ld(TW, 1u << (a.s - 2)));             // omega_4
-        y1 = f29_sub10(s0, s1);
-        y2 = f29_add(d0, d1);
-        y3 = f29_sub10(d0, d1);
-      } else {
-        const Fr29 d0 = f29_mul(f29_sub10_lazy(u0, u2), tw_ld(TW, lo << (a.s - 1 - st)));
-        const Fr29 d1 = f29_mul(f29_sub10_lazy(u1, u3), tw_ld(TW, (lo + hq) << (a.s - 1 - st)));
-        const Fr29 w = tw_ld(TW, lo << (a.s - st));
-        y1 = f29_mul(f29_sub10_lazy(s0, s1), w);
-        y2 = f29_add(d0, d1);
-        y3 = f29_mul(f29_sub10_lazy(d0, d1), w);
-      }
-      lds_st(L, e0, f29_reduce_weak(f29_add(s0, s1)));
-      lds_st(L, e1, y1);
-      lds_st(L, e2, y2);
-      lds_st(L, e3, y3);
+      Fr29 x0 = lds_ld(L, e0), x1 = lds_ld(L, e1), x2 = lds_ld(L, e2), x3 = lds_ld(L, e3);
+      if (last_block) f29_dif4_last(x0, x1, x2, x3, tw_ld(TW, 1u << (a.s - 2)));  // omega_4
+      else f29_dif4(x0, x1, x2, x3, tw_ld(TW, lo << (a.s - 1 - st)), tw_ld(TW, (lo + hq) << (a.s - 1 - st)), tw_ld(TW, lo << (a.s - st)));
+      lds_st(L, e0, x0);
+      lds_st(L, e1, x1);
+      lds_st(L, e2, x2);
+      lds_st(L, e3, x3);
     }
     __syncthreads();
   }
@@ -282,8 +277,8 @@ __global__ __launch_bounds__(NTT_THREADS) void ntt_step_kernel(NttPassArgs a) {
       uint32_t i_next = (lo_base + c) >> sh_next;
       uint32_t Jp = J_prev + (j << a.log_prev);
       uint32_t ex = (i_next * Jp) << log_g;
-      x = ex != 0 ? f29_mul(x, fr29_unpack(tw_lookup(a.tw, ex, log_n))) : f29_reduce_weak(x);
-      st_fr(out + in_base + (size_t)j * row_stride + c, pack_out(x));
+      x = ex != 0 ? f29_mul(x, fr29_unpack(tw_lookup(a.tw, ex, log_n, a.tw_full))) : f29_reduce_weak(x);
+      st_fr(out + in_base + (size_t)j * row_stride + c, pack_between(x));
     }
   } else {
     const size_t out_base = (size_t)(j1_blk << a.log_c) + (a.npass == 3 ? ((size_t)j2 << a.log_n1) : 0);
@@ -330,7 +325,7 @@ int get_twiddles(amdzk_ctx* ctx, uint32_t log_n, const uint64_t omega[4], Fr** o
     *out = it->second;
     return AMDZK_OK;
   }
-  uint32_t count = log_n == 0 ? 1 : (1u << (log_n - 1));
+  uint32_t count = log_n == 0 ? 1 : log_n <= TW_FULL_MAX_LOG_N ? (1u << log_n) : (1u << (log_n - 1));
   Fr* d = nullptr;
   ZK_HIP(ctx, hipMalloc((void**)&d, (size_t)count * sizeof(Fr)));
   Fr w;
@@ -407,6 +402,7 @@ int zk_ntt_ex(amdzk_ctx* ctx, const Fr* d_in, size_t in_stride, Fr* d_out, size_
   NttPassArgs a;
   memset(&a, 0, sizeof(a));
   a.tw = tw;
+  a.tw_full = log_n >= 1 && log_n <= TW_FULL_MAX_LOG_N;
   a.log_n = log_n;
   a.npass = plan.npass;
   a.log_n1 = plan.s[0];
@@ -467,6 +463,7 @@ int zk_ntt_ex(amdzk_ctx* ctx, const Fr* d_in, size_t in_stride, Fr* d_out, size_
     dim3 grid((uint32_t)(n >> tile_elems_log), (uint32_t)ncols, nz), block(threads);
     const size_t tile_elems = (size_t)1 << tile_elems_log;
     size_t shmem = (tile_elems + ((size_t)1 << a.s) / 2 + 1) * 9 * sizeof(uint32_t);  // limbs, see ntt_step_kernel
+    shmem += env_u32(last ? "AMDZK_NTT_LDS_PAD_LAST" : "AMDZK_NTT_LDS_PAD_FIRST", 0);  // occupancy experiments
     if (last) {
       if (shmem > 65536) ZK_HIP(ctx, hipFuncSetAttribute((const void*)ntt_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
       ZK_LAUNCH(ctx, "ntt_step_last", ntt_step_kernel<true>, grid, block, shmem, a);

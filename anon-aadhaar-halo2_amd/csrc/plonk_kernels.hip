@@ -1034,14 +1034,15 @@ int zk_sort_keys(amdzk_ctx* ctx, Fr* d_cols, size_t ncols, uint32_t n, size_t co
 // permute_expression_pair for L lookups: A (sorted inputs, in place), Ts (sorted tables), S out.
 // flags: 4 u32 arrays of flag_stride per lookup: rep | used | rank_rep | rank_left (flag_stride >= u+1).
 int zk_lookup_permute(amdzk_ctx* ctx, Fr* A, Fr* Ts, Fr* S, Fr* left, size_t L, uint32_t n, uint32_t u, uint32_t* flags, size_t flag_stride,
-                      int* d_err) {
+                      int* d_err, size_t tables_presorted) {
   if (L == 0) return AMDZK_OK;
+  if (tables_presorted > L) ZK_FAIL(ctx, AMDZK_E_INVALID, "lookup_permute: more presorted tables than lookups");
   uint32_t* rep = flags;
   uint32_t* used = flags + L * flag_stride;
   uint32_t* rank_rep = flags + 2 * L * flag_stride;
   uint32_t* rank_left = flags + 3 * L * flag_stride;
   ZK_TRY(zk_sort_keys(ctx, A, L, n, n));
-  ZK_TRY(zk_sort_keys(ctx, Ts, L, n, n));
+  if (tables_presorted < L) ZK_TRY(zk_sort_keys(ctx, Ts + tables_presorted * n, L - tables_presorted, n, n));
   ZK_HIP(ctx, hipMemsetAsync(flags, 0, 2 * L * flag_stride * sizeof(uint32_t), ctx->stream));
   dim3 grid((u + 255) / 256, (unsigned)L), block(256);
   ZK_LAUNCH(ctx, "lookup_mark", lookup_mark_kernel, grid, block, 0, A, Ts, (size_t)n, u, rep, used, flag_stride, d_err);

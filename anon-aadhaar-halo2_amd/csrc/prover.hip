@@ -199,6 +199,14 @@ struct amdzk_pk {
     std::vector<Set> sets;                          // first seen first
   } mo;
   Fr *lk_ts = nullptr, *lk_left = nullptr;  // lookup permutation: sorted tables, leftovers [L][n]
+  // The first lk_const lookups have ONE table expression over fixed columns and constants only: their compressed table
+  // does not depend on theta or on the witness, so its sorted canonical form is made once at keygen ([lk_const][n]).
+  uint32_t lk_const = 0;
+  Fr* lk_ts_const = nullptr;
+  // (Permuting the lookups among them that also have ONE input expression before theta exists, on lane C beside the advice
+  // commitment, was measured and dropped: a proof alone took 19.1-19.3 ms with it against 18.7-19.0 without, 21
+  // proofs x 3 alternating runs, profiles/r03q_constant_tables_and_early_lookups.txt — the small sort kernels stretch the
+  // chip-filling commitment by more than they save behind theta.)
   uint32_t* lk_flags = nullptr;              // [4][L][n+8]
   int* d_err = nullptr;
   // misc small device buffers (blinding uploads, points, evals, coefs) and pointer-table scratch, one slice per lane:
@@ -311,20 +319,34 @@ int d2d(amdzk_ctx* ctx, void* dst, const void* src, size_t bytes) {
 // of both come back zero (the caller blinds them). T: the compressed tables (read only). Ts / left: [L][n] scratch,
 // flags: 4 x L x (n + 8) u32 scratch. Canonical keys (numeric order = upstream's Ord for Fr), rows >= usable padded
 // with an all-ones sentinel (> any canonical value) so the power-of-two sort leaves the real rows in front.
+// Ts_sorted: the first `presorted` tables as keygen left them (canonical, padded, sorted), or null. Enqueues the whole
+// permutation on ctx's stream; d_err receives 1 + the index of a lookup whose input is not in its table (0: none) —
+// zk_permute_check reads it.
 int zk_permute_expression_pairs(amdzk_ctx* ctx, Fr* A, const Fr* T, Fr* Ts, Fr* S, Fr* left, uint32_t* flags, int* d_err, size_t L, uint32_t n,
-                                uint32_t usable) {
+                                uint32_t usable, const Fr* Ts_sorted = nullptr, size_t presorted = 0) {
   if (L == 0) return AMDZK_OK;
-  ZK_TRY(d2d(ctx, Ts, T, L * n * 32));
+  if (presorted > L || (presorted && !Ts_sorted)) ZK_FAIL(ctx, AMDZK_E_INVALID, "permute_expression_pairs: bad presorted tables");
+  const size_t rest = L - presorted;
+  Fr* Tr = Ts + presorted * n;
+  if (presorted) ZK_TRY(d2d(ctx, Ts, Ts_sorted, presorted * n * 32));
   ZK_TRY(amdzk_fr_to_repr_dev(ctx, A, L * n));
-  ZK_TRY(amdzk_fr_to_repr_dev(ctx, Ts, L * n));
   ZK_HIP(ctx, hipMemset2DAsync(A + usable, (size_t)n * 32, 0xFF, (size_t)(n - usable) * 32, L, ctx->stream));
-  ZK_HIP(ctx, hipMemset2DAsync(Ts + usable, (size_t)n * 32, 0xFF, (size_t)(n - usable) * 32, L, ctx->stream));
+  if (rest) {
+    ZK_TRY(d2d(ctx, Tr, T + presorted * n, rest * n * 32));
+    ZK_TRY(amdzk_fr_to_repr_dev(ctx, Tr, rest * n));
+    ZK_HIP(ctx, hipMemset2DAsync(Tr + usable, (size_t)n * 32, 0xFF, (size_t)(n - usable) * 32, rest, ctx->stream));
+  }
   ZK_HIP(ctx, hipMemsetAsync(d_err, 0, sizeof(int), ctx->stream));
-  ZK_TRY(zk_lookup_permute(ctx, A, Ts, S, left, L, n, usable, flags, (size_t)n + 8, d_err));
+  ZK_TRY(zk_lookup_permute(ctx, A, Ts, S, left, L, n, usable, flags, (size_t)n + 8, d_err, presorted));
   ZK_HIP(ctx, hipMemset2DAsync(A + usable, (size_t)n * 32, 0, (size_t)(n - usable) * 32, L, ctx->stream));
   ZK_HIP(ctx, hipMemset2DAsync(S + usable, (size_t)n * 32, 0, (size_t)(n - usable) * 32, L, ctx->stream));
   ZK_TRY(amdzk_fr_from_raw_dev(ctx, A, L * n));
   ZK_TRY(amdzk_fr_from_raw_dev(ctx, S, L * n));
+  return AMDZK_OK;
+}
+
+// the word zk_permute_expression_pairs left in d_err, once its work on ctx's stream is done
+int zk_permute_check(amdzk_ctx* ctx, const int* d_err) {
   int herr = 0;
   ZK_TRY(d2h(ctx, &herr, d_err, sizeof(int)));
   if (herr) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: lookup %d input not in table (ConstraintSystemFailure)", herr - 1);
@@ -1149,19 +1171,32 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
   auto colkind_slot_lag = [&](std::pair<int, int> kc) { return kc.first == 0 ? pk->sl_adv(kc.second) : kc.first == 1 ? pk->sl_fixed(kc.second) : pk->sl_inst(kc.second); };
   const uint32_t r0 = pk->rots.index(0), r1 = pk->rots.index(1), rm1 = pk->rots.index(-1), rlast = pk->rots.index(-(int32_t)(pk->bf + 1));
   auto COL = [&](uint32_t slot, uint32_t r) { return (slot << 8) | r; };
-  // (1) lookup compression: ci[l], ct[l]
+  // (1) lookup compression: ci[l], ct[l]. Leading lookups whose table is one expression over fixed columns and constants
+  // (amdzk_pk::lk_const) get ct[l] once, below.
   {
     Program& pr = pk->prog_compress;
     uint32_t e = pk->num_gates;
+    for (uint32_t l = 0; l < L && !getenv("AMDZK_NO_TABLE_CACHE"); l++) {
+      const uint32_t ni = pk->lookup_shape[l].first, nt = pk->lookup_shape[l].second;
+      bool constant = nt == 1;
+      if (constant)
+        for (uint32_t w : pk->exprs[e + ni]) constant = constant && (w >> 24) != XOP_ADVICE && (w >> 24) != XOP_INSTANCE;
+      if (!constant) break;
+      pk->lk_const++;
+      e += ni + nt;
+    }
+    e = pk->num_gates;
     for (uint32_t l = 0; l < L; l++) {
       pr.piece();
       KG_TRY(emit_compressed(ctx, pk, pr, e, pk->lookup_shape[l].first));
       pr.op(OP_STORE, 2 * l);
       pr.pop();
       e += pk->lookup_shape[l].first;
-      KG_TRY(emit_compressed(ctx, pk, pr, e, pk->lookup_shape[l].second));
-      pr.op(OP_STORE, 2 * l + 1);
-      pr.pop();
+      if (l >= pk->lk_const) {
+        KG_TRY(emit_compressed(ctx, pk, pr, e, pk->lookup_shape[l].second));
+        pr.op(OP_STORE, 2 * l + 1);
+        pr.pop();
+      }
       e += pk->lookup_shape[l].second;
     }
     std::vector<Fr*> outs(2 * L);
@@ -1384,6 +1419,27 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
         fprintf(stderr, "[amdzk]   product -> product: %s -> %s x %zu\n", names[kv.first.first], names[kv.first.second], kv.second);
       }
     fprintf(stderr, "[amdzk]   products directly followed by a product: %zu\n", mm);
+  }
+  // Constant tables (amdzk_pk::lk_const): ct[l] evaluated here, once, and its canonical, padded, sorted form kept
+  if (pk->lk_const) {
+    const uint32_t cnt = pk->lk_const, usable = (uint32_t)n - (pk->bf + 1);
+    KG_TRY(dalloc(ctx, pk, &pk->lk_ts_const, (size_t)cnt * n));
+    Program pr;
+    uint32_t e = pk->num_gates;
+    for (uint32_t l = 0; l < cnt; l++) {
+      pr.piece();
+      KG_TRY(emit_expr(ctx, pk, pr, pk->exprs[e + pk->lookup_shape[l].first]));
+      pr.op(OP_STORE, 2 * l + 1);
+      pr.pop();
+      e += pk->lookup_shape[l].first + 1;
+    }
+    KG_TRY(upload_program(ctx, pk, pr, false));
+    KG_TRY(run_program(ctx, pk, pr, false, pk->d_outs_compress, nullptr, "expr_const_tables"));
+    KG_TRY(d2d(ctx, pk->lk_ts_const, pk->ct, (size_t)cnt * n * 32));
+    KG_TRY(amdzk_fr_to_repr_dev(ctx, pk->lk_ts_const, (size_t)cnt * n));
+    ZK_HIP(ctx, hipMemset2DAsync(pk->lk_ts_const + usable, (size_t)n * 32, 0xFF, (size_t)(n - usable) * 32, cnt, ctx->stream));
+    KG_TRY(zk_sort_keys(ctx, pk->lk_ts_const, cnt, n, n));
+    ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   }
   // l_active coset = 1 - (l_last + l_blind): lactive_c holds l_blind's coset; tiny one-off program
   {
@@ -1692,7 +1748,8 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     ZK_TRY(run_program(ctx, pk, pk->prog_compress, false, pk->d_outs_compress, nullptr, "expr_lookup_compress"));
     ZK_TRY(d2d(ctx, pk->la(), pk->ci, (size_t)L * n * 32));
     ZK_TRY(zk_permute_expression_pairs(ctx, pk->la(), pk->ct, pk->lk_ts, pk->ls(), pk->lk_left, pk->lk_flags, pk->d_err, L, (uint32_t)n,
-                                       (uint32_t)usable));
+                                       (uint32_t)usable, pk->lk_ts_const, pk->lk_const));
+    ZK_TRY(zk_permute_check(ctx, pk->d_err));
     tick("  lookup: device permute");
     // RNG order per lookup: a' tail, s' tail, blind(a'), blind(s')
     std::vector<Fr> ta((size_t)L * (bf + 1)), ts((size_t)L * (bf + 1));
@@ -2244,8 +2301,10 @@ int amdzk_permute_expression_pair_dev(amdzk_ctx* ctx, void* d_inputs, const void
   char* ws = nullptr;  // Ts[L][n] | left[L][n] | flags 4 x L x (n + 8) | err
   const size_t L = nlookups, col = L * (size_t)n * 32, fl = 4 * L * ((size_t)n + 8) * 4;
   ZK_TRY(zk_ws_reserve(ctx, 5, 2 * col + fl + 256, (void**)&ws));
-  return zk_permute_expression_pairs(ctx, (Fr*)d_inputs, (const Fr*)d_tables, (Fr*)ws, (Fr*)d_permuted_tables_out, (Fr*)(ws + col),
-                                     (uint32_t*)(ws + 2 * col), (int*)(ws + 2 * col + fl), L, n, usable);
+  if (L == 0) return AMDZK_OK;
+  ZK_TRY(zk_permute_expression_pairs(ctx, (Fr*)d_inputs, (const Fr*)d_tables, (Fr*)ws, (Fr*)d_permuted_tables_out, (Fr*)(ws + col),
+                                     (uint32_t*)(ws + 2 * col), (int*)(ws + 2 * col + fl), L, n, usable));
+  return zk_permute_check(ctx, (const int*)(ws + 2 * col + fl));
 }
 
 }  // extern "C"

@@ -195,7 +195,7 @@ class GpuProver:
     def prove(self, w, wi, seed):
         return self.plonk.create_proof(self.ctxs[w], self.pks[w], self.inst[wi], self.d_adv[wi], seed=seed)
 
-    def latency(self, seed, serial, reps=3):
+    def latency(self, seed, serial, reps=int(os.environ.get("AMDZK_BENCH_LATENCY_REPS", "3"))):
         """One proof alone on the GPU with a key of the given mode — default: the proof's independent work on three streams
         (lanes); serial: one stream, as in rounds 1-2 — `reps` times after one untimed proof: (median ms, the last proof)."""
         want_flags = self.plonk.KEYGEN_SERIAL if serial else None  # None: the library's default (lanes, unless AMDZK_SERIAL=1)

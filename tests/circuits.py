@@ -93,7 +93,9 @@ def high_degree_circuit(plonk, k=5, power=9, seed=1):
     return c
 
 
-def lookup_circuit(plonk, k=5, seed=1):
+def lookup_circuit(plonk, k=5, seed=1, tables="range_first"):
+    """tables: 'range_first' (the one-column fixed table is lookup 0), 'pair_first' (it is lookup 1, behind the two-column
+    one), 'range_expr' (lookup 0's table is the expression 2 * t_rng - t_rng over the fixed column: same values)."""
     rnd = np.random.RandomState(seed)
     cs = plonk.ConstraintSystem()
     a, b, c_ = cs.advice_column(), cs.advice_column(), cs.advice_column()
@@ -104,9 +106,14 @@ def lookup_circuit(plonk, k=5, seed=1):
         cs.enable_equality(col)
     cs.create_gate(lambda m: [m.query_selector(q_mul) * (m.query_advice(a, 0) * m.query_advice(b, 0) - m.query_advice(c_, 0)),
                               m.query_selector(q_add) * (m.query_advice(a, 0) + m.query_advice(b, 1) - m.query_advice(c_, 0))])
-    cs.lookup(lambda m: [(m.query_selector(q_rng) * m.query_advice(a, 0), m.query_fixed(t_rng, 0))])
-    cs.lookup(lambda m: [(m.query_selector(q_pair) * m.query_advice(b, 0), m.query_fixed(t_x, 0)),
-                         (m.query_selector(q_pair) * m.query_advice(c_, 0), m.query_fixed(t_y, 0))])
+    def rng_table(m):
+        t = m.query_fixed(t_rng, 0)
+        return t * 2 - t if tables == "range_expr" else t
+    lk_range = lambda m: [(m.query_selector(q_rng) * m.query_advice(a, 0), rng_table(m))]
+    lk_pair = lambda m: [(m.query_selector(q_pair) * m.query_advice(b, 0), m.query_fixed(t_x, 0)),
+                         (m.query_selector(q_pair) * m.query_advice(c_, 0), m.query_fixed(t_y, 0))]
+    for lk in ((lk_pair, lk_range) if tables == "pair_first" else (lk_range, lk_pair)):
+        cs.lookup(lk)
     c = Circuit(cs, k)
     c.assembly = plonk.Assembly(c.n, len(cs.permutation_columns))
     u = c.usable

@@ -160,6 +160,60 @@ int main() {
     if (fails) return 1;
   }
   printf("weak reduction ok\n");
+  // --- ntt.hip's radix-4 blocks (f29_dif4 / f29_dif4_last): the lazy first-round sums against the same block with every
+  // intermediate normalised, on random inputs and on the largest operands the kernel's bounds allow (elements below 4p
+  // with all-ones low limbs, canonical twiddles with all-ones low limbs); the bound checks are hard failures here
+  {
+    auto canon = [](Fr29 x) {
+      x = f29_reduce_weak(f29_norm(x));
+      int64_t bw = 0;
+      Fr29 t2;
+      for (int i = 0; i < 9; i++) { int64_t d = (int64_t)x.l[i] - (int64_t)Fr29P::p(i) + bw; t2.l[i] = i < 8 ? ((uint32_t)d & F29_MASK) : (uint32_t)d; bw = d >> 29; }
+      return bw < 0 ? x : t2;
+    };
+    auto same = [&](const Fr29& a, const Fr29& b) {
+      Fr29 ca = canon(a), cb = canon(b);
+      for (int i = 0; i < 9; i++) if (ca.l[i] != cb.l[i]) return false;
+      return true;
+    };
+    auto rnd_elem = [&](int mode, uint32_t top_units) {  // normalised, below top_units * p
+      Fr29 v;
+      for (int i = 0; i < 8; i++) v.l[i] = mode == 1 ? F29_MASK : mode == 2 ? 0u : ((uint32_t)rnd() & F29_MASK);
+      const uint32_t lim = top_units * Fr29P::p(8) - 1;  // top limb strictly below top_units * p8: value below top_units * p
+      v.l[8] = mode == 1 ? lim : mode == 2 ? 0u : (uint32_t)(rnd() % (lim + 1));
+      return v;
+    };
+    for (int t = 0; t < 30000; t++) {
+      const int mx = t < 81 ? t : -1;  // the first 81 cases walk the extreme / zero patterns of the four elements
+      Fr29 x[4], tw[3];
+      for (int j = 0; j < 4; j++) x[j] = rnd_elem(mx < 0 ? 0 : (mx / (j == 0 ? 1 : j == 1 ? 3 : j == 2 ? 9 : 27)) % 3, 4);
+      for (int j = 0; j < 3; j++) tw[j] = rnd_elem(t % 5 == 0 ? 1 : 0, 1);
+      // reference: the block with normalised intermediates
+      const Fr29 s0 = f29_add(x[0], x[2]), s1 = f29_add(x[1], x[3]);
+      const Fr29 d0 = f29_mul(f29_sub10_lazy(x[0], x[2]), tw[0]), d1 = f29_mul(f29_sub10_lazy(x[1], x[3]), tw[1]);
+      const Fr29 r0 = f29_reduce_weak(f29_add(s0, s1)), r1 = f29_mul(f29_sub10_lazy(s0, s1), tw[2]), r2 = f29_add(d0, d1),
+                 r3 = f29_mul(f29_sub10_lazy(d0, d1), tw[2]);
+      Fr29 y0 = x[0], y1 = x[1], y2 = x[2], y3 = x[3];
+      f29_dif4(y0, y1, y2, y3, tw[0], tw[1], tw[2]);
+      bool ok = same(y0, r0) && same(y1, r1) && same(y2, r2) && same(y3, r3);
+      for (int i = 0; i < 8; i++) ok = ok && !((y0.l[i] | y1.l[i] | y2.l[i] | y3.l[i]) >> 29);
+      ok = ok && y0.l[8] <= Fr29P::p(8) + 176 && y1.l[8] < 2 * Fr29P::p(8) + 2 && y2.l[8] < 4 * Fr29P::p(8) + 4 && y3.l[8] < 2 * Fr29P::p(8) + 2;
+      // the last block
+      const Fr29 e0 = f29_sub10(x[0], x[2]), e1 = f29_mul(f29_sub10_lazy(x[1], x[3]), tw[0]);
+      const Fr29 q1 = f29_sub10(s0, s1), q2 = f29_add(e0, e1), q3 = f29_sub10(e0, e1);
+      Fr29 z0 = x[0], z1 = x[1], z2 = x[2], z3 = x[3];
+      f29_dif4_last(z0, z1, z2, z3, tw[0]);
+      ok = ok && same(z0, r0) && same(z1, q1) && same(z2, q2) && same(z3, q3);
+      for (int i = 0; i < 8; i++) ok = ok && !((z0.l[i] | z1.l[i] | z2.l[i] | z3.l[i]) >> 29);
+      ok = ok && z1.l[8] < 18 * Fr29P::p(8) + 18 && z2.l[8] < 16 * Fr29P::p(8) + 16 && z3.l[8] < 24 * Fr29P::p(8) + 24;
+      // and each result still goes through the product / weak reduction it leaves the tile by
+      (void)f29_mul(z1, tw[1]); (void)f29_mul(z2, tw[1]); (void)f29_mul(z3, tw[1]);
+      (void)f29_reduce_weak(z1); (void)f29_reduce_weak(z2); (void)f29_reduce_weak(z3);
+      if (!ok) { fails++; printf("radix-4 block %d\n", t); if (fails > 5) return 1; }
+    }
+    if (fails) return 1;
+  }
+  printf("radix-4 blocks ok\n");
   // --- points: k*G for small k with the 32-bit code
   G1Affine g;
   g.x = Fq::one();

@@ -39,6 +39,24 @@ def setup(ctx, pkg, plonk, oracle, c, transcript_repr_int=123456789, flags=None)
     return params, pk, d_adv, inst
 
 
+@pytest.mark.parametrize("tables", ["range_first", "pair_first", "range_expr"])
+def test_constant_tables_sorted_at_keygen(ctx, pkg, plonk, oracle, tables, monkeypatch):
+    """A leading lookup whose table is one expression over fixed columns has its sorted table made at keygen
+    (amdzk_pk::lk_const). The proof bytes are the oracle's with such a lookup in front, with it behind a theta-compressed
+    one (so the cache does not apply), with a table expression rather than a plain column — and with the cache off."""
+    c = circuits.lookup_circuit(plonk, 6, seed=21, tables=tables)
+    opk = PR.keygen(c.desc, c.fixed, c.assembly.mapping, TAU, transcript_repr=123456789)
+    want = PR.create_proof(opk, c.instances, c.advice, seed=5)
+    for cache in (True, False):
+        if not cache:
+            monkeypatch.setenv("AMDZK_NO_TABLE_CACHE", "1")
+        for flags in (None, plonk.KEYGEN_SERIAL):
+            params, pk, d_adv, inst = setup(ctx, pkg, plonk, oracle, c, flags=flags)
+            assert plonk.create_proof(ctx, pk, inst, d_adv, seed=5) == want
+            assert plonk.create_proof(ctx, pk, inst, d_adv, seed=5) == want
+            d_adv.free(); pk.free(); params.free()
+
+
 def vk_from_device(pk, c, transcript_repr_int=123456789):
     f, p = pk.commitments()
     return PR.VerifyingKey(c.desc, [zu.point_to_ints(x) for x in f], [zu.point_to_ints(x) for x in p], TAU, transcript_repr_int)
@@ -179,7 +197,15 @@ def test_lookup_failure_is_reported(ctx, pkg, plonk, oracle):
     params, pk, d_adv, inst = setup(ctx, pkg, plonk, oracle, c)
     with pytest.raises(pkg.AmdzkError) as e:
         plonk.create_proof(ctx, pk, inst, d_adv, seed=5)
-    assert "not in table" in str(e.value)
+    assert "lookup 0 input not in table" in str(e.value)
+    d_adv.free(); pk.free(); params.free()
+    # the two-column lookup (index 1, behind a lookup whose table was sorted at keygen)
+    c = circuits.lookup_circuit(plonk, 5, seed=4)
+    c.advice[2][c.usable - 1] = (c.advice[2][c.usable - 1] + 1) % circuits.R  # (b, c) no longer a (x, x^2) pair of the table
+    params, pk, d_adv, inst = setup(ctx, pkg, plonk, oracle, c)
+    with pytest.raises(pkg.AmdzkError) as e:
+        plonk.create_proof(ctx, pk, inst, d_adv, seed=5)
+    assert "lookup 1 input not in table" in str(e.value)
     d_adv.free(); pk.free(); params.free()
 
 

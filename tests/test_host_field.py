@@ -22,14 +22,15 @@ def test_fp29_field_and_point_formulas_match_32bit_code():
     level-1 MSM kernel) compiled for the host with the documented bounds as hard failures
     (FP29_CHECK_BOUNDS): radix round trips, products, sums, differences and packing on 20k operands, the
     scalar field's mixed-radix product (data in radix 2^256 times a radix-2^261 constant, as the NTT uses it),
-    3000 random accumulation chains (identity, doubling, cancellation, negated points) and 3000 random
-    reduction trees of full additions / doublings against bn254.cuh."""
+    3000 random accumulation chains (identity, doubling, cancellation, negated points), 3000 random
+    reduction trees of full additions / doublings against bn254.cuh, and the NTT's radix-4 blocks (lazy first-round sums)
+    against the same blocks with normalised intermediates, at random and at the largest operands the bounds allow."""
     src = os.path.join(ROOT, "tests", "native", "fp29_check.cpp")
     with tempfile.TemporaryDirectory() as d:
         exe = os.path.join(d, "fp29")
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", exe, src])
         out = subprocess.check_output([exe], text=True)
-    assert "Fq29 field ok" in out and "Fr29 mixed radix ok" in out and "weak reduction ok" in out and "G1X29 ok" in out and "FAILED" not in out
+    assert "Fq29 field ok" in out and "Fr29 mixed radix ok" in out and "weak reduction ok" in out and "radix-4 blocks ok" in out and "G1X29 ok" in out and "FAILED" not in out
 
 
 def test_fp29_constants_are_reproducible():
