@@ -199,10 +199,13 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_limbs_kernel(ExprArgs 
   auto hot = [&](uint32_t k) -> Fr29 { return fr29_unpack(ld_fr(a.cols[a.hot[k]] + row)); };
   uint32_t sp = 0;  // elements on the stack, including tos
   const size_t blk_base = row & ~a.mask;
-  const ExprProgPtr prog = (ExprProgPtr)a.prog;
+  // piece blockIdx.y of the program (prover.hip finalize_limb_program) accumulates into its own h
+  const uint32_t first = a.nparts ? a.part_start[blockIdx.y] : 0u, prog_len = a.nparts ? a.part_len[blockIdx.y] : a.prog_len;
+  const ExprProgPtr prog = (ExprProgPtr)a.prog + first;
+  Fr* const h_out = a.h_out + (size_t)blockIdx.y * a.nrows;
   ExprWord cur = expr_word(prog, 0), nxt = expr_word(prog, 1);
   Fr pre = expr_fetch(cur, row, blk_base, a.mask);
-  for (uint32_t pc = 0; pc < a.prog_len; pc++) {
+  for (uint32_t pc = 0; pc < prog_len; pc++) {
     const uint32_t op = cur.op_arg >> 24, arg = cur.op_arg & 0xffffffu;
     // the operand of this instruction (if it has one) as limbs: unpacking is also what frees `pre` for the next fetch
     const Fr29 x = fr29_unpack(pre);
@@ -305,8 +308,8 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_limbs_kernel(ExprArgs 
         const uint32_t k = arg & 7;
         if (k == 3) g = f29_mul(g, hotx);
         else if (k < 3) g = f29_mul(g, hot(k));
-        if (!(arg & 16)) g = f29_add(g, fr29_unpack(ld_fr(a.h_out + row)));  // bit 4: the first group of the program
-        st_fr(a.h_out + row, f29_pack_canonical<FrP>(f29_reduce_weak(g)));
+        if (!(arg & 16)) g = f29_add(g, fr29_unpack(ld_fr(h_out + row)));  // bit 4: the first group of the program (piece)
+        st_fr(h_out + row, f29_pack_canonical<FrP>(f29_reduce_weak(g)));
       } break;
       case OP_STORE:  // the host reduced tos below 2p
         st_fr(a.outs[arg] + row, f29_pack_canonical<FrP>(tos));
@@ -892,11 +895,24 @@ int zk_expr_eval(amdzk_ctx* ctx, const ExprArgs& a, uint32_t depth, const char* 
   return AMDZK_OK;
 }
 
+// h[row] += h[p * rows + row], p = 1 .. nparts - 1 (canonical values): the pieces of a cut h(X) program
+__global__ void sum_parts_kernel(Fr* h, size_t rows, uint32_t nparts) {
+  const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  Fr acc = ld_fr(h + row);
+  for (uint32_t p = 1; p < nparts; p++) acc = add(acc, ld_fr(h + (size_t)p * rows + row));
+  st_fr(h + row, acc);
+}
+
 int zk_expr_eval_limbs(amdzk_ctx* ctx, const ExprArgs& a, uint32_t depth, const char* name) {
   size_t shmem = (size_t)(depth ? depth : 1) * EXPR_THREADS * 9 * sizeof(uint32_t) + (size_t)17 * EXPR_THREADS * sizeof(uint64_t);
-  const dim3 grid((unsigned)((a.nrows + EXPR_THREADS - 1) / EXPR_THREADS)), block(EXPR_THREADS);
+  if (a.nparts > (uint32_t)EXPR_MAX_PARTS) ZK_FAIL(ctx, AMDZK_E_INVALID, "expr_eval_limbs: too many program parts");
+  if (a.nparts > 1 && !a.h_out) ZK_FAIL(ctx, AMDZK_E_INVALID, "expr_eval_limbs: a cut program needs h_out (nparts x nrows)");
+  const dim3 grid((unsigned)((a.nrows + EXPR_THREADS - 1) / EXPR_THREADS), a.nparts ? a.nparts : 1u), block(EXPR_THREADS);
   if (shmem > 65536) ZK_HIP(ctx, hipFuncSetAttribute((const void*)expr_eval_limbs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
   ZK_LAUNCH(ctx, name, expr_eval_limbs_kernel, grid, block, shmem, a);
+  if (a.nparts > 1)
+    ZK_LAUNCH(ctx, "sum_parts", sum_parts_kernel, dim3((unsigned)((a.nrows + 255) / 256)), dim3(256), 0, a.h_out, a.nrows, a.nparts);
   return AMDZK_OK;
 }
 

@@ -69,9 +69,9 @@ struct ExprArgs {
   // 1: everything the program touches is in radix 2^261 (32 x the value in the ordinary form): products use
   //    fp29.cuh's in-place 29-bit product. The prover runs the h(X) program this way (extended domain only).
   uint32_t radix261;
-  // Lagrange-domain programs only (expr_eval_kernel): the program as `nparts` independent pieces (each leaves the
-  // stack empty), piece p = instructions [part_start[p], part_start[p] + part_len[p]), run by the workgroups with
-  // blockIdx.y = p. n = 2^15 rows are 512 wavefronts — half a wavefront per SIMD walking a long program one dependent
+  // The program as `nparts` independent pieces (each leaves the stack empty), piece p = instructions
+  // [part_start[p], part_start[p] + part_len[p]), run by the workgroups with blockIdx.y = p. The limb interpreter's
+  // pieces (the h(X) program cut by the host) each accumulate into h_out + p * nrows, summed into h_out afterwards. n = 2^15 rows are 512 wavefronts — half a wavefront per SIMD walking a long program one dependent
   // product after the other; cut at set / lookup boundaries the same work is 8 x as many wavefronts. 0: the whole program.
   uint32_t nparts;
   uint32_t part_start[EXPR_MAX_PARTS], part_len[EXPR_MAX_PARTS];

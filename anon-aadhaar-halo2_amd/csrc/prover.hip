@@ -554,8 +554,13 @@ int emit_compressed(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, uint32_t first, u
 //     bounds would leave the reduction's range.
 // Bounds: a column, constant or hot value is below 1 (canonical); a product is below 2; a sum adds the bounds; a
 // difference a - b adds K to a's; the weak reduction gives 1.0002; a flushed group sum(bounds) / 169.3 + 1.
+// nparts > 1 cuts the finalised program into that many independent pieces of about equal length (Program::piece_starts):
+// a piece is a run of terms of the group order, closed by its own flush, and its first flush overwrites ITS h (bit 4) —
+// the interpreter runs piece p on the workgroups with blockIdx.y = p into h + p * rows, and the pieces' sums are added
+// afterwards (h is linear in the terms). One proof alone fills the chip's wavefront slots only that way.
 // Returns the number of terms (= the powers of y of amdzk_pk::d_ypow that the OP_WACC instructions point at).
-uint32_t finalize_limb_program(Program& pr) {
+constexpr uint32_t H_PARTS_MAX = 8;
+uint32_t finalize_limb_program(Program& pr, uint32_t nparts = 1) {
   const double LIM = 160.0, RED = 1.01, GROUP_LIM = 169.0 * 30.0;  // a flushed group stays below ~31 p (+ h, canonical)
   struct Term {
     std::vector<uint32_t> words;
@@ -681,6 +686,13 @@ uint32_t finalize_limb_program(Program& pr) {
     fin.push_back((OP_WFLUSH << 24) | g | (first ? 16u : 0u));
     first = false;
   };
+  size_t term_words = 0;
+  for (const Term& t : terms) term_words += t.words.size() + 1;
+  if (terms.empty() || !tail.empty()) nparts = 1;  // (programs that store columns are not cut)
+  pr.piece_starts.clear();
+  uint32_t part = 0;
+  size_t part_begin = 0;
+  if (nparts > 1) pr.piece_starts.push_back(0);
   for (uint32_t g = 0; g <= 4; g++) {
     double sum = 0;
     uint32_t since_carry = 0;
@@ -691,6 +703,18 @@ uint32_t finalize_limb_program(Program& pr) {
         flush(g);
         sum = 0;
         since_carry = 0;
+        open = false;
+      }
+      // the next piece starts where this one has its share of the instructions
+      if (part + 1 < nparts && fin.size() - part_begin >= (term_words + nparts - 1) / nparts) {
+        if (open) flush(g);
+        sum = 0;
+        since_carry = 0;
+        open = false;
+        part++;
+        part_begin = fin.size();
+        pr.piece_starts.push_back((uint32_t)fin.size());
+        first = true;
       }
       fin.insert(fin.end(), t.words.begin(), t.words.end());
       const bool carry = ++since_carry == 6;  // a column holds six un-carried terms
@@ -801,6 +825,14 @@ int run_program(amdzk_ctx* ctx, amdzk_pk* pk, Program& pr, bool extended, Fr* co
     }
     if (begin != total) a.nparts = 0;  // (cannot happen: the last part runs to the end) — fall back to one part
   }
+  if (extended && pr.piece_starts.size() > 1) {  // the pieces finalize_limb_program cut: one per blockIdx.y, h_out + p * rows each
+    if (pr.piece_starts.size() > (size_t)EXPR_MAX_PARTS) ZK_FAIL(ctx, AMDZK_E_INVALID, "program: too many pieces");
+    for (size_t i = 0; i < pr.piece_starts.size(); i++) {
+      a.part_start[i] = pr.piece_starts[i];
+      a.part_len[i] = (i + 1 < pr.piece_starts.size() ? pr.piece_starts[i + 1] : (uint32_t)pr.words.size()) - pr.piece_starts[i];
+    }
+    a.nparts = (uint32_t)pr.piece_starts.size();
+  }
   for (int i = 0; i < EXPR_HOT; i++) a.hot[i] = EXPR_NO_SLOT;
   if (extended && pr.uses_hot) {
     a.hot[0] = pk->se_l0();
@@ -817,24 +849,6 @@ Fr rotate_omega(const amdzk_pk* pk, const Fr& x, int rot) {
   return rot >= 0 ? mul(x, pow_u64(pk->omega, (uint64_t)rot)) : mul(x, pow_u64(pk->omega_inv, (uint64_t)(-rot)));
 }
 
-// arithmetic::lagrange_interpolate: coefficients of the polynomial of degree < m through (points, evals)
-std::vector<Fr> lagrange_interpolate(const std::vector<Fr>& pts, const std::vector<Fr>& evals) {
-  size_t m = pts.size();
-  std::vector<Fr> out(m, Fr::zero());
-  for (size_t j = 0; j < m; j++) {
-    std::vector<Fr> num(1, Fr::one());
-    Fr den = Fr::one();
-    for (size_t k2 = 0; k2 < m; k2++) {
-      if (k2 == j) continue;
-      num.insert(num.begin(), Fr::zero());
-      for (size_t t = 0; t + 1 < num.size(); t++) num[t] = sub(num[t], mul(pts[k2], num[t + 1]));
-      den = mul(den, sub(pts[j], pts[k2]));
-    }
-    Fr sc = mul(evals[j], inv(den));
-    for (size_t t = 0; t < num.size(); t++) out[t] = add(out[t], mul(num[t], sc));
-  }
-  return out;
-}
 Fr eval_small(const std::vector<Fr>& poly, const Fr& x) {
   Fr acc = Fr::zero();
   for (size_t i = poly.size(); i-- > 0;) acc = add(mul(acc, x), poly[i]);
@@ -1008,7 +1022,7 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
   KG_TRY(dalloc(ctx, pk, &pk->lk_flags, (size_t)4 * L * (n + 8)));
   KG_TRY(dalloc(ctx, pk, &pk->d_err, 1));
   KG_TRY(dalloc(ctx, pk, &pk->rnd, n));
-  KG_TRY(dalloc(ctx, pk, &pk->hq, ext));
+  KG_TRY(dalloc(ctx, pk, &pk->hq, (size_t)H_PARTS_MAX * ext));  // one h per piece of the cut h(X) program (finalize_limb_program)
   KG_TRY(dalloc(ctx, pk, &pk->hpieces, (size_t)pk->qdeg * n));
   KG_TRY(dalloc(ctx, pk, &pk->hpoly, n));
   const size_t nfrac = std::max<size_t>(std::max<size_t>(ns, L), 1);
@@ -1394,7 +1408,17 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
   KG_TRY(upload_program(ctx, pk, pk->prog_compress, false));
   KG_TRY(upload_program(ctx, pk, pk->prog_pfrac, false));
   KG_TRY(upload_program(ctx, pk, pk->prog_lfrac, false));
-  pk->h_terms = finalize_limb_program(pk->prog_h);
+  {
+    // pieces of the h(X) program: 6 by default. One piece is 1.5 wavefronts per SIMD at k = 15 (3 cosets x 2^15 rows) and
+    // the interpreter alone took 2.30 ms of a lone proof's critical path; 8 pieces 1.70 ms. Latency of one proof, median
+    // of 15, two runs each on one box: 1 piece 18.34 / 18.39 ms, 4: 17.71 / 17.86, 6: 17.61 / 17.78, 8: 17.63 / 17.46;
+    // 10 proofs in flight: 78.0 / 76.7, 77.8 / 78.3, 78.2 / 78.5, 78.0 / 77.6 proofs/s (no difference).
+    // AMDZK_H_PARTS=1..8 for experiments.
+    const char* e = getenv("AMDZK_H_PARTS");
+    uint32_t parts = e ? (uint32_t)atoi(e) : 6u;
+    parts = parts < 1 ? 1 : parts > H_PARTS_MAX ? H_PARTS_MAX : parts;
+    pk->h_terms = finalize_limb_program(pk->prog_h, parts);
+  }
   pk->h_term_beta_pow = pk->prog_h.term_beta;
   KG_TRY(dalloc(ctx, pk, &pk->d_ypow, (size_t)std::max<uint32_t>(pk->h_terms, 1)));
   KG_TRY(upload_program(ctx, pk, pk->prog_h, true));
@@ -2066,29 +2090,65 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     Fr v = T.squeeze_challenge();
     trace_fr("shplonk_y", ys);
     trace_fr("shplonk_v", v);
+    // Per set i with points p_t (ascending): R_i(X) = sum_j y^j R_ij(X), R_ij the interpolation of polynomial j's
+    // evaluations. Interpolation is linear, so R_i is the interpolation of E_i[t] = sum_j y^j eval_ij[t]:
+    // R_i = sum_t E_i[t] c_it prod_{s != t} (X - p_s), c_it = 1 / prod_{s != t} (p_t - p_s) — one host product per
+    // evaluation instead of one small interpolation per polynomial, and ONE field inversion (batched over all c_it)
+    // instead of one per basis polynomial and point: the host used to spend 0.26 ms here with the GPU idle.
     std::vector<std::vector<Fr>> set_pts(nr);
-    std::vector<std::vector<std::vector<Fr>>> lows(nr);  // [set][commitment] low-degree equivalent
+    std::vector<std::vector<uint32_t>> set_order(nr);  // positions in rot_ids, by ascending point
+    std::vector<std::vector<Fr>> set_c(nr);            // c_it
+    {
+      std::vector<Fr> dens;
+      for (size_t i = 0; i < nr; i++) {
+        const amdzk_pk::Multiopen::Set& st = mo.sets[i];
+        const size_t m = st.rot_ids.size();
+        std::vector<uint32_t>& order = set_order[i];
+        order.resize(m);
+        for (size_t t = 0; t < m; t++) order[t] = (uint32_t)t;
+        std::sort(order.begin(), order.end(), [&](uint32_t t1, uint32_t t2) { return by_point(st.rot_ids[t1], st.rot_ids[t2]); });
+        for (size_t t = 0; t < m; t++) set_pts[i].push_back(rot_pt[st.rot_ids[order[t]]]);
+        for (size_t t = 0; t < m; t++) {
+          Fr den = Fr::one();
+          for (size_t s2 = 0; s2 < m; s2++)
+            if (s2 != t) den = mul(den, sub(set_pts[i][t], set_pts[i][s2]));
+          dens.push_back(den);  // non-zero: the points of a set are distinct
+        }
+      }
+      // Montgomery's trick: prefix products, one inversion, walk back
+      std::vector<Fr> pre(dens.size() + 1, Fr::one());
+      for (size_t k2 = 0; k2 < dens.size(); k2++) pre[k2 + 1] = mul(pre[k2], dens[k2]);
+      Fr acc = inv(pre[dens.size()]);
+      std::vector<Fr> dinv(dens.size());
+      for (size_t k2 = dens.size(); k2-- > 0;) {
+        dinv[k2] = mul(acc, pre[k2]);
+        acc = mul(acc, dens[k2]);
+      }
+      size_t at = 0;
+      for (size_t i = 0; i < nr; i++)
+        for (size_t t = 0; t < set_pts[i].size(); t++) set_c[i].push_back(dinv[at++]);
+    }
+    std::vector<std::vector<Fr>> lowsum(nr);  // R_i, coefficients
     for (size_t i = 0; i < nr; i++) {
       const amdzk_pk::Multiopen::Set& st = mo.sets[i];
-      const size_t m = st.rot_ids.size();
-      std::vector<uint32_t> order(m);  // positions in rot_ids, by ascending point
-      for (size_t t = 0; t < m; t++) order[t] = (uint32_t)t;
-      std::sort(order.begin(), order.end(), [&](uint32_t t1, uint32_t t2) { return by_point(st.rot_ids[t1], st.rot_ids[t2]); });
-      for (size_t t = 0; t < m; t++) set_pts[i].push_back(rot_pt[st.rot_ids[order[t]]]);
-      // Lagrange basis of the set's points, once per set: low_ij = sum_t evals_t * basis_t
-      std::vector<std::vector<Fr>> basis(m);
-      for (size_t t = 0; t < m; t++) {
-        std::vector<Fr> unit(m, Fr::zero());
-        unit[t] = Fr::one();
-        basis[t] = lagrange_interpolate(set_pts[i], unit);
-      }
+      const size_t np = set_pts[i].size();
+      std::vector<Fr> E(np, Fr::zero());
+      Fr yp = Fr::one();
       for (size_t j = 0; j < st.polys.size(); j++) {
-        std::vector<Fr> low(m, Fr::zero());
-        for (size_t t = 0; t < m; t++) {
-          const Fr e = evals[st.ev_idx[j][order[t]]];
-          for (size_t d = 0; d < m; d++) low[d] = add(low[d], mul(e, basis[t][d]));
+        for (size_t t = 0; t < np; t++) E[t] = add(E[t], mul(yp, evals[st.ev_idx[j][set_order[i][t]]]));
+        yp = mul(yp, ys);
+      }
+      lowsum[i].assign(np, Fr::zero());
+      for (size_t t = 0; t < np; t++) {
+        std::vector<Fr> num(1, Fr::one());  // prod_{s != t} (X - p_s), ascending coefficients
+        for (size_t s2 = 0; s2 < np; s2++) {
+          if (s2 == t) continue;
+          num.push_back(Fr::zero());
+          for (size_t d = num.size() - 1; d > 0; d--) num[d] = sub(num[d - 1], mul(set_pts[i][s2], num[d]));
+          num[0] = neg(mul(set_pts[i][s2], num[0]));
         }
-        lows[i].push_back(std::move(low));
+        const Fr w = mul(E[t], set_c[i][t]);
+        for (size_t d = 0; d < np; d++) lowsum[i][d] = add(lowsum[i][d], mul(w, num[d]));
       }
     }
     // L_i = sum_j y^j P_ij ; N_i = (L_i - R_i) / prod_t (X - p_t), R_i = sum_j y^j R_ij. The division runs once, not once
@@ -2108,10 +2168,8 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
       if (m > pk->ptrs_cap || m > pk->small_cap / 2) ZK_FAIL(ctx, AMDZK_E_NOMEM, "create_proof: rotation set too large");
       std::vector<Fr> cf(m);
       Fr cur = Fr::one();
-      std::vector<Fr> lowsum(np, Fr::zero());
       for (size_t j = 0; j < m; j++) {
         cf[j] = cur;
-        for (size_t t = 0; t < lows[i][j].size(); t++) lowsum[t] = add(lowsum[t], mul(cur, lows[i][j][t]));
         cur = mul(cur, ys);
       }
       amdzk_ctx* ln = lanes3[i % 3];
@@ -2122,14 +2180,11 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
       Fr* Li = pk->sets_L + i * n;
       LN_TRY(ln, zk_lincomb(ln, (const Fr* const*)pk->ptrs_l[li], pk->small_l[li], (uint32_t)m, Li, n, false));
       for (size_t t = 0; t < np; t++) {
-        Fr den = Fr::one();
-        for (size_t s2 = 0; s2 < np; s2++)
-          if (s2 != t) den = mul(den, sub(set_pts[i][t], set_pts[i][s2]));
         q_src.push_back(Li);
         q_dst.push_back(pk->sets_Q + q_dst.size() * n);
         q_root.push_back(set_pts[i][t]);
-        q_coef.push_back(mul(vpow, inv(den)));
-        for (size_t d = 0; d < maxm; d++) q_low.push_back(d < np ? lowsum[d] : Fr::zero());
+        q_coef.push_back(mul(vpow, set_c[i][t]));
+        for (size_t d = 0; d < maxm; d++) q_low.push_back(d < np ? lowsum[i][d] : Fr::zero());
       }
       vpow = mul(vpow, v);
     }
@@ -2163,11 +2218,7 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
       for (uint32_t r : super)
         if (!std::binary_search(mo.sets[i].rot_ids.begin(), mo.sets[i].rot_ids.end(), r)) zi = mul(zi, sub(u, rot_pt[r]));
       if (i == 0) z0 = zi;
-      Fr ri = Fr::zero(), yp = Fr::one();
-      for (size_t j = 0; j < lows[i].size(); j++) {
-        ri = add(ri, mul(yp, eval_small(lows[i][j], u)));
-        yp = mul(yp, ys);
-      }
+      const Fr ri = eval_small(lowsum[i], u);  // R_i(u) = sum_j y^j R_ij(u)
       Fr w = mul(cur, zi);
       pp[i] = pk->sets_L + i * n;
       cf[i] = w;

@@ -19,7 +19,7 @@ def check(words):
     AssertionError. Every power of y a WACC names must be used exactly once (a term dropped or doubled by the grouping
     would go unnoticed by a bound walk alone)."""
     st, depth, nred, nfused = [], 0, 0, 0
-    wide, seen, uncarried, flushes = 0.0, set(), 0, 0
+    wide, seen, uncarried, flushes, pieces = 0.0, set(), 0, 0, 0
     for pc, w in enumerate(words):
         op = NAME.get(w >> 24)
         where = "pc %d %s" % (pc, op)
@@ -67,7 +67,10 @@ def check(words):
         elif op == "WFLUSH":                                 # g = redc(wide) [* hot]; h = (h +) g, stored canonical
             k = w & 7
             assert k <= 4 and (w & 0xFFFFFF) & ~0x17 == 0, where
-            assert bool(w & 16) == (flushes == 0), where + ": exactly the first flush overwrites h"
+            # bit 4: this flush overwrites h — the first flush of the program, or of a further piece of a cut program
+            # (pieces run side by side into their own h and are summed afterwards: prover.hip finalize_limb_program)
+            assert (w & 16) or flushes > 0, where + ": the first flush must overwrite h"
+            pieces += 1 if w & 16 else 0
             flushes += 1
             g = wide / 169.3 + 1.0                           # f29_wide_redc: T / 2^261 + p
             assert g < VALUE_RANGE, where
@@ -94,4 +97,5 @@ def check(words):
     assert not st, "values left on the stack"
     assert wide == 0.0, "terms left in the wide accumulator"
     assert seen == set(range(len(seen))), "the powers of y are not 0..K-1"
+    check.pieces = pieces  # how many flushes overwrite h (1, or the pieces of a cut program)
     return depth, nred, nfused

@@ -345,7 +345,17 @@ def test_h_program_of_the_metric_shape_respects_every_bound(ctx, pkg, oracle):
     # nsets = 118 / (degree - 2) = 59; lookups: 5 per lookup
     nsets = (118 + c.desc["cs_degree"] - 3) // (c.desc["cs_degree"] - 2)
     assert nterms == 93 + (2 + nsets - 1 + nsets) + 5 * 24
-    assert names.count("WFLUSH") == 4 and "MUL_HOT" not in names  # l_0, l_last, l_active groups + the gates
+    # l_0, l_last, l_active groups + the gates; the program is cut into six pieces (one more flush wherever a cut falls
+    # inside a group) of about equal length
+    assert LC.check.pieces == 6 and 4 <= names.count("WFLUSH") <= 4 + 5 and "MUL_HOT" not in names
+    starts, prev_end = [], 0  # a piece begins behind the previous flush and its first flush carries bit 4
+    for i, w in enumerate(words):
+        if (w >> 24) == LC.OPS["WFLUSH"]:
+            if w & 16:
+                starts.append(prev_end)
+            prev_end = i + 1
+    lens = [b - a for a, b in zip(starts, starts[1:] + [len(words)])]
+    assert len(lens) == 6 and max(lens) < 1.5 * len(words) / 6 and min(lens) > 0.5 * len(words) / 6, lens
     # stack: the set's two shared values w_j, the two running products and one copy in flight (round 3: the factored
     # permutation terms); 4 products per 2-column set instead of 8 multiplications by constants and running products
     assert depth <= 5

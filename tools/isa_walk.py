@@ -104,11 +104,13 @@ class Walker:
         self.memory = {}
         put = lambda a, v, n=1: [self.memory.__setitem__(a + 4 * i, (v >> (32 * i)) & M32) for i in range(n)]
         put(KA + 0x00, PB, 2); put(KA + 0x08, len(words)); put(KA + 0x10, CB, 2); put(KA + 0x18, OUTS, 2)
-        # ExprArgs (plonk_kernels.hpp): prog, prog_len, cols, outs, h_out, mask, nrows, hot[4], radix261
+        # ExprArgs (plonk_kernels.hpp): prog, prog_len, cols, outs, h_out, mask, nrows, hot[4], radix261, nparts, part_start[8], part_len[8]
         put(KA + 0x20, HOUT, 2); put(KA + 0x28, (1 << 15) - 1, 2); put(KA + 0x30, 3 << 15, 2)
         for i in range(4):
             put(KA + 0x38 + 4 * i, i)
         put(KA + 0x48, 1)
+        for i in range(17):
+            put(KA + 0x4C + 4 * i, 0)  # nparts = 0 (the whole program), part_start[8], part_len[8]
         for i in range(64):
             put(CB + 8 * i, COLDATA + (i << 24), 2)
             put(OUTS + 8 * i, COLDATA + ((64 + i) << 24), 2)
@@ -218,7 +220,7 @@ class Walker:
             self.exec = self.exec if src is None else self.exec & src  # divergent guard: this wave's rows are all live
             self.scc = int(self.exec != 0)
             return None
-        if op in ("s_add_i32", "s_add_u32", "s_sub_i32", "s_sub_u32", "s_addc_u32", "s_mul_i32", "s_lshl_b32", "s_lshr_b32", "s_ashr_i32"):
+        if op in ("s_add_i32", "s_add_u32", "s_sub_i32", "s_sub_u32", "s_addc_u32", "s_mul_i32", "s_mul_hi_u32", "s_lshl_b32", "s_lshr_b32", "s_ashr_i32"):
             a, b = R(o[1]), R(o[2])
             if a is None or b is None:
                 W(o[0], None)
@@ -235,6 +237,8 @@ class Walker:
                 self.scc = int(r < 0)
             elif k == "mul_i32":
                 r = a * b
+            elif k == "mul_hi_u32":
+                r = ((a & M32) * (b & M32)) >> 32
             elif k == "lshl_b32":
                 r = a << (b & 31)
             elif k == "lshr_b32":
