@@ -206,7 +206,8 @@ struct amdzk_pk {
   // (Permuting the lookups among them that also have ONE input expression before theta exists, on lane C beside the advice
   // commitment, was measured and dropped: a proof alone took 19.1-19.3 ms with it against 18.7-19.0 without, 21
   // proofs x 3 alternating runs, profiles/r03q_constant_tables_and_early_lookups.txt — the small sort kernels stretch the
-  // chip-filling commitment by more than they save behind theta.)
+  // chip-filling commitment by more than they save behind theta; started behind its level-1 kernel instead they stretch
+  // its bucket reduction and lane B's transforms: 18.0-18.2 ms against 17.6-17.95.)
   uint32_t* lk_flags = nullptr;              // [4][L][n+8]
   int* d_err = nullptr;
   // misc small device buffers (blinding uploads, points, evals, coefs) and pointer-table scratch, one slice per lane:
