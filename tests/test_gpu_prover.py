@@ -150,6 +150,21 @@ def test_lanes_and_serial_mode_give_the_same_bytes(ctx, pkg, plonk, oracle):
         assert got["lanes"][1] == PR.create_proof(opk, c.instances, c.advice, seed=34, multiopen="gwc")
 
 
+def test_h_program_pieces_give_the_same_bytes(ctx, pkg, plonk, oracle, monkeypatch):
+    """The h(X) program is cut into pieces that run side by side into their own h and are summed (6 by
+    default, AMDZK_H_PARTS at keygen): h is linear in the constraint terms, so every cut gives the oracle's bytes — 1 to 8
+    pieces, more pieces than a small program has terms included, on a circuit with lookups and on the SquareCircuit."""
+    for c in (circuits.lookup_circuit(plonk, 6, seed=13), circuits.square_circuit(plonk, 4, signal=5)):
+        opk = PR.keygen(c.desc, c.fixed, c.assembly.mapping, TAU, transcript_repr=123456789)
+        want = PR.create_proof(opk, c.instances, c.advice, seed=41)
+        for parts in (1, 2, 3, 5, 8, 64):
+            monkeypatch.setenv("AMDZK_H_PARTS", str(parts))
+            params, pk, d_adv, inst = setup(ctx, pkg, plonk, oracle, c)
+            assert plonk.create_proof(ctx, pk, inst, d_adv, seed=41) == want, parts
+            d_adv.free(); pk.free(); params.free()
+        monkeypatch.delenv("AMDZK_H_PARTS")
+
+
 @pytest.mark.parametrize("power,flags", [(9, 0), (9, 1), (4, 0), (16, 0)])
 def test_high_degree_gate_bytes_equal_oracle(ctx, pkg, plonk, oracle, power, flags):
     """Constraint degree 10 (9 quotient pieces: more cosets than the templated recombination kernel's 8 — the generic
