@@ -92,3 +92,25 @@ def test_integration_md_ffi_block_is_the_headers():
     assert "pub fn amdzk_ntt_fr_batch(ctx: *mut Ctx, cols: *const *mut u64, ncols: usize, log_n: u32, omega: *const u64, flags: u32) -> c_int;" in block
     assert "pub fn amdzk_last_error(ctx: *const Ctx) -> *const c_char;" in block
     assert "pub fn amdzk_destroy(ctx: *mut Ctx);" in block
+
+
+def test_integration_md_lists_every_environment_variable_the_library_reads():
+    """INTEGRATION.md's table of environment variables against the sources: every AMDZK_* name a getenv / env_u32 call in
+    csrc/ reads is documented there, and the table names nothing the library does not read."""
+    import re
+    csrc = os.path.join(ROOT, "anon-aadhaar-halo2_amd", "csrc")
+    used = set()
+    for fn in os.listdir(csrc):
+        if fn.endswith((".hip", ".hpp", ".cuh")):
+            text = open(os.path.join(csrc, fn)).read()
+            used |= set(re.findall(r'(?:getenv|env_u32)\(\s*"(AMDZK_[A-Z0-9_]+)"', text))
+            for pair in re.findall(r'env_u32\([^"]*\?\s*"(AMDZK_[A-Z0-9_]+)"\s*:\s*"(AMDZK_[A-Z0-9_]+)"', text):  # env_u32(c ? "A" : "B", ...)
+                used |= set(pair)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = doc[doc.index("## Environment variables the library reads"):doc.index("## Python (ctypes) binding")]
+    table = "\n".join(ln for ln in sec.splitlines() if ln.startswith("|"))
+    listed = set(re.findall(r"`(AMDZK_[A-Z0-9_]+)", table))
+    flags = {"AMDZK_KEYGEN_SERIAL", "AMDZK_KEYGEN_FULL_COSETS"}  # header constants the table's text mentions
+    assert used, "no getenv found: the pattern is stale"
+    assert used - listed == set(), "undocumented: %s" % sorted(used - listed)
+    assert listed - used - flags == set(), "documented but not read: %s" % sorted(listed - used - flags)
