@@ -332,31 +332,11 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_accum_seg_kernel(AccArgs a) {
       } while (e >= b_end);
     }
     if (FIRST) {
-#if defined(AMDZK_L1_PREFETCH)
-      // The table point of entry e + 1 is TOUCHED (one dword, into a register nobody reads) before the addition of entry e:
-      // a random 64-byte gather from the 42 MB window table takes about a third of an addition, and three wavefronts per
-      // SIMD do not always cover it for each other; the gather of entry e then hits the cache line its touch brought in.
-      // The compiler inserts no wait for a load it cannot see, and would drain this one with its next vmcnt(0): so every
-      // load of the iteration is completed first (the empty asm "uses" the point and the next id), the touch is issued
-      // behind them, and its own wait sits behind the addition, when it has long returned.
-      const uint32_t id = ent[e];
-      uint32_t id1 = ent[min(e + 1, end - 1)];
-      G1Affine p = ld_aff(a.table + (id & 0x7fffffffu));
-      asm volatile("" : "+v"(p.x.l[0]), "+v"(p.x.l[1]), "+v"(p.x.l[2]), "+v"(p.x.l[3]), "+v"(p.x.l[4]), "+v"(p.x.l[5]), "+v"(p.x.l[6]), "+v"(p.x.l[7]),
-                        "+v"(p.y.l[0]), "+v"(p.y.l[1]), "+v"(p.y.l[2]), "+v"(p.y.l[3]), "+v"(p.y.l[4]), "+v"(p.y.l[5]), "+v"(p.y.l[6]), "+v"(p.y.l[7]),
-                        "+v"(id1));
-      uint32_t touched;
-      asm volatile("global_load_dword %0, %1, off" : "=v"(touched) : "v"(a.table + (id1 & 0x7fffffffu)) : "memory");
-#else
       const uint32_t id = ent[e];
       G1Affine p = ld_aff(a.table + (id & 0x7fffffffu));
-#endif
       const bool p_inf = p.is_inf();
       if (id >> 31) p.y = neg(p.y);  // negating a canonical value does not depend on the Montgomery radix
       acc = x29_add_affine(acc, fq29_unpack(p.x), fq29_unpack(p.y), p_inf);
-#if defined(AMDZK_L1_PREFETCH)
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(touched) : : "memory");
-#endif
     } else {
       acc = x29_add(acc, ld_x29(in + e));
     }
