@@ -569,9 +569,9 @@ def roofline(prover, desc):
             "avg_launch_ms": round(total_ms / launches, 4), "avg_launch_ms_profile": pmc.get("avg_ms_profile"),
             "launches_per_step": launches,
             # what the kernel is actually limited by: VALU issue. cycles per VALU wave-instruction =
-            # launch time x 1024 SIMDs x 2.4 GHz / SQ_INSTS_VALU per launch; ~5 means the SIMDs issue back to back
-            # (v_mad_u64_u32 issues at 4.3 cycles at best, plain 32-bit VALU at 2.5-4.2: profiles/r02k_instruction_rates_mb_isa.jsonl)
-            "valu_wave_insts_per_launch": pmc.get("valu"),
+            # launch time x 1024 SIMDs x 2.4 GHz / SQ_INSTS_VALU per launch (of a proof's launches); the product block alone
+            # reaches 4.3 with three wavefronts per SIMD, the kernel 5.3 (profiles/r03w_wide_product_and_l1_prefetch.txt)
+            "valu_wave_insts_per_launch": pmc.get("valu"), "valu_wave_insts_source": pmc.get("valu_source", "whole-run average" if pmc.get("valu") else None),
             "valu_issue_cycles_per_inst": round(avg_s * 1024 * 2.4e9 / pmc["valu"], 2) if pmc.get("valu") else None,
             "issue_bound": issue_bound(pmc, avg_s),
             "gpu_busy_ms_per_step": round(gpu_ms, 3), "wall_ms_profiled_step": round(wall_prof, 3),
@@ -676,6 +676,12 @@ def pmc_counters(kernel):
                         if mad_share is not None and kernel == "msm_accum_l1":
                             out["mad_share"] = mad_share
                         out["avg_ms_profile"] = steady_avg_ms(path, names.get(kernel, kernel))
+                        # instructions per launch of a PROOF's launches (the summary's whole-run average also holds keygen's
+                        # larger commitment batches: 3.70e8 against 3.36e8 for the level-1 kernel)
+                        sv = steady_avg_ms(path, names.get(kernel, kernel), "SQ_INSTS_VALU_per_launch")
+                        if sv:
+                            out["valu"] = round(sv)
+                            out["valu_source"] = "steady-state proof"
                         return out
         except OSError:
             continue
@@ -775,17 +781,18 @@ def k22_stress(prover, want_cpu):
     return out
 
 
-def steady_avg_ms(summary_path, kernel):
-    """Average launch time of `kernel` over ONE steady-state proof of the rocprofv3 --kernel-trace pass that belongs to a
-    PMC summary (profiles/<tag>_kernel_stats_steady.csv, written by tools/summarize_prof.py next to it)."""
+def steady_avg_ms(summary_path, kernel, column="avg_ms"):
+    """Average launch time (or, column = "SQ_INSTS_VALU_per_launch", the VALU wave-instructions per launch) of `kernel` over
+    ONE steady-state proof of the rocprofv3 passes that belong to a PMC summary (profiles/<tag>_kernel_stats_steady.csv,
+    written by tools/summarize_prof.py next to it)."""
     import csv
     path = summary_path.replace("_kernel_summary.csv", "_kernel_stats_steady.csv")
     try:
         with open(path) as f:
             rows = [ln for ln in f if not ln.startswith("#")]
         for row in csv.DictReader(rows):
-            if row["kernel"] == kernel:
-                return round(float(row["avg_ms"]), 4)
+            if row["kernel"] == kernel and row.get(column):
+                return round(float(row[column]), 4)
     except (OSError, KeyError, ValueError):
         pass
     return None

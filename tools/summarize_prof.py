@@ -95,13 +95,32 @@ def main():
             a, b = marks[-2], marks[-1]
             srows = c.execute("select name, count(*), sum(duration), avg(duration) from kernels where start >= ? and start < ? "
                               "group by name order by sum(duration) desc", (a, b)).fetchall()
+            # the same proof in the instruction-count pass (same command, same dispatch sequence): VALU per launch there —
+            # the whole-run averages of the summary also hold keygen's larger commitment batches
+            steady_valu = {}
+            ci = db(src, "insts")
+            if ci:
+                seq = ci.execute("select dispatch_id, name, sum(counter_value) from pmc_events where counter_name = 'SQ_INSTS_VALU' "
+                                 "group by dispatch_id, name order by dispatch_id").fetchall()
+                im = [d for d, name, _ in seq if "chacha20_fr_random" in name]
+                if len(im) >= 2:
+                    tot, cnt = collections.Counter(), collections.Counter()
+                    for d, name, v in seq:
+                        if im[-2] <= d < im[-1]:
+                            tot[short(name)] += v
+                            cnt[short(name)] += 1
+                    steady_valu = {k: (tot[k] / cnt[k], cnt[k]) for k in tot}
             with open(os.path.join("profiles", tag + "_kernel_stats_steady.csv"), "w") as o:
                 o.write("# kernel_src_sha256=%s\n" % _b.kernel_src_hash())
                 o.write("# one steady-state proof of the rocprofv3 --kernel-trace pass (serial keys: no overlapping kernels), wall %.3f ms, "
-                        "sum of kernel durations %.3f ms\n" % ((b - a) / 1e6, sum(r[2] for r in srows) / 1e6))
-                o.write("kernel,launches,total_ms,avg_ms\n")
-                for name, calls, tot, avg in srows:
-                    o.write('"%s",%d,%.4f,%.4f\n' % (short(name), calls, tot / 1e6, avg / 1e6))
+                        "sum of kernel durations %.3f ms; SQ_INSTS_VALU per launch from the same proof of the --pmc pass\n" % ((b - a) / 1e6, sum(r[2] for r in srows) / 1e6))
+                o.write("kernel,launches,total_ms,avg_ms,SQ_INSTS_VALU_per_launch,cycles_per_valu_inst_1024_simds_2p4GHz\n")
+                for name, calls, tot_ns, avg in srows:
+                    k = short(name)
+                    sv = steady_valu.get(k)
+                    ok = sv is not None and sv[1] == calls and sv[0] > 0
+                    o.write('"%s",%d,%.4f,%.4f,%s,%s\n' % (k, calls, tot_ns / 1e6, avg / 1e6, "%.0f" % sv[0] if ok else "",
+                                                        "%.2f" % (avg * 1e-9 * 1024 * 2.4e9 / sv[0]) if ok else ""))
             print(open(os.path.join("profiles", tag + "_kernel_stats_steady.csv")).read())
     pmc = {}
     per_counter = collections.defaultdict(lambda: collections.defaultdict(float))
