@@ -756,20 +756,31 @@ __device__ __forceinline__ bool key_eq(const Fr& a, const Fr& b) { return a == b
 
 // k_from..k_to (inclusive, powers of two): runs every (k, j) step with j < SORT_TILE inside LDS.
 // full = 1: k from 2 (local sort of each tile); full = 0: only the j < SORT_TILE tail of stage k_to.
-__global__ __launch_bounds__(1024) void bitonic_lds_kernel(Fr* data, size_t col_stride, uint32_t n, uint32_t k_from, uint32_t k_to) {
+// Columns blockIdx.y < ncols_a are data + y * col_stride, the others data_b + (y - ncols_a) * col_stride: two batches of
+// columns (the lookups' inputs and their tables) sort in one launch sequence — a workgroup's time is the latency of its
+// own ~80 barrier-separated stages whatever the grid, so the second batch rides along.
+__global__ __launch_bounds__(1024) void bitonic_lds_kernel(Fr* data, Fr* data_b, uint32_t ncols_a, size_t col_stride, uint32_t n, uint32_t k_from,
+                                                           uint32_t k_to) {
   extern __shared__ uint4 lds_raw[];
   Fr* L = reinterpret_cast<Fr*>(lds_raw);
   const uint32_t tile = n < SORT_TILE ? n : SORT_TILE;
   const uint32_t base = blockIdx.x * tile, t = threadIdx.x;
-  Fr* col = data + (size_t)blockIdx.y * col_stride;
+  Fr* col = blockIdx.y < ncols_a ? data + (size_t)blockIdx.y * col_stride : data_b + (size_t)(blockIdx.y - ncols_a) * col_stride;
   for (uint32_t i = t; i < tile; i += blockDim.x) L[i] = ld_fr(col + base + i);
-  __syncthreads();
+  // A stage with j <= 64 touches, from wavefront w, only elements [128 w', 128 w' + 128) for the two runs of 64 pairs it
+  // owns (p and p + blockDim.x): consecutive stages of that kind hand data from a wavefront to itself, and LDS executes a
+  // wavefront's accesses in order — the workgroup barrier is only needed next to a stage with j >= 128 (57 of the 78 stages
+  // of a 4096-key tile run without one). Needs blockDim.x to be a multiple of 64 and pairs p, p + blockDim.x, ... per thread.
+  bool prev_wide = true;  // the load phase above wrote across wavefronts
   for (uint32_t k = k_from; k <= k_to; k <<= 1) {
     uint32_t jstart = k >> 1;
     if (jstart >= tile) jstart = tile >> 1;
     for (uint32_t j = jstart; j >= 1; j >>= 1) {
+      const bool wide = j >= 128;
+      if (wide || prev_wide) __syncthreads();
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       for (uint32_t p = t; p < (tile >> 1); p += blockDim.x) {
-        uint32_t i = ((p / j) * 2 * j) + (p % j), l = i + j;
+        const uint32_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), l = i + j;  // j is a power of two
         bool asc = (((base + i) & k) == 0);
         Fr a = L[i], b = L[l];
         bool sw = asc ? key_less(b, a) : key_less(a, b);
@@ -778,17 +789,19 @@ __global__ __launch_bounds__(1024) void bitonic_lds_kernel(Fr* data, size_t col_
           L[l] = a;
         }
       }
-      __syncthreads();
+      prev_wide = wide;
     }
   }
+  __syncthreads();
   for (uint32_t i = t; i < tile; i += blockDim.x) st_fr(col + base + i, L[i]);
 }
 
-__global__ __launch_bounds__(256) void bitonic_global_kernel(Fr* data, size_t col_stride, uint32_t n, uint32_t k, uint32_t j) {
-  Fr* col = data + (size_t)blockIdx.y * col_stride;
+__global__ __launch_bounds__(256) void bitonic_global_kernel(Fr* data, Fr* data_b, uint32_t ncols_a, size_t col_stride, uint32_t n, uint32_t k,
+                                                             uint32_t j) {
+  Fr* col = blockIdx.y < ncols_a ? data + (size_t)blockIdx.y * col_stride : data_b + (size_t)(blockIdx.y - ncols_a) * col_stride;
   uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= (n >> 1)) return;
-  uint32_t i = ((p / j) * 2 * j) + (p % j), l = i + j;
+  const uint32_t i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), l = i + j;  // j is a power of two
   bool asc = ((i & k) == 0);
   Fr a = ld_fr(col + i), b = ld_fr(col + l);
   bool sw = asc ? key_less(b, a) : key_less(a, b);
@@ -1031,20 +1044,29 @@ int zk_scatter_rows(amdzk_ctx* ctx, Fr* d_dst, size_t col_stride, size_t row0, c
   return AMDZK_OK;
 }
 
-// Sort ncols columns of n (power of two) canonical keys ascending, in place.
-int zk_sort_keys(amdzk_ctx* ctx, Fr* d_cols, size_t ncols, uint32_t n, size_t col_stride) {
+// Sort ncols_a columns at d_cols and ncols_b columns at d_cols_b (n keys each, n a power of two, canonical, ascending, in
+// place; both batches with the same column stride) in one sequence of launches.
+int zk_sort_keys2(amdzk_ctx* ctx, Fr* d_cols, size_t ncols_a, Fr* d_cols_b, size_t ncols_b, uint32_t n, size_t col_stride) {
+  const size_t ncols = ncols_a + ncols_b;
   if (ncols == 0 || n < 2) return AMDZK_OK;
+  if (ncols > 65535) ZK_FAIL(ctx, AMDZK_E_INVALID, "sort_keys: more than 65535 columns");
   const uint32_t tile = n < SORT_TILE ? n : SORT_TILE;
   const size_t shmem = (size_t)tile * sizeof(Fr);
   const unsigned threads = tile / 2 >= 1024 ? 1024 : (tile / 2 >= 64 ? tile / 2 : 64);
+  const uint32_t na = (uint32_t)ncols_a;
   if (shmem > 65536) ZK_HIP(ctx, hipFuncSetAttribute((const void*)bitonic_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-  ZK_LAUNCH(ctx, "sort_bitonic_lds", bitonic_lds_kernel, dim3(n / tile, (unsigned)ncols), dim3(threads), shmem, d_cols, col_stride, n, 2u, tile);
+  ZK_LAUNCH(ctx, "sort_bitonic_lds", bitonic_lds_kernel, dim3(n / tile, (unsigned)ncols), dim3(threads), shmem, d_cols, d_cols_b, na, col_stride, n, 2u, tile);
   for (uint32_t k = tile << 1; k <= n && k != 0; k <<= 1) {
     for (uint32_t j = k >> 1; j >= tile; j >>= 1)
-      ZK_LAUNCH(ctx, "sort_bitonic_global", bitonic_global_kernel, dim3((n / 2 + 255) / 256, (unsigned)ncols), dim3(256), 0, d_cols, col_stride, n, k, j);
-    ZK_LAUNCH(ctx, "sort_bitonic_lds", bitonic_lds_kernel, dim3(n / tile, (unsigned)ncols), dim3(threads), shmem, d_cols, col_stride, n, k, k);
+      ZK_LAUNCH(ctx, "sort_bitonic_global", bitonic_global_kernel, dim3((n / 2 + 255) / 256, (unsigned)ncols), dim3(256), 0, d_cols, d_cols_b, na, col_stride, n,
+                k, j);
+    ZK_LAUNCH(ctx, "sort_bitonic_lds", bitonic_lds_kernel, dim3(n / tile, (unsigned)ncols), dim3(threads), shmem, d_cols, d_cols_b, na, col_stride, n, k, k);
   }
   return AMDZK_OK;
+}
+// Sort ncols columns of n (power of two) canonical keys ascending, in place.
+int zk_sort_keys(amdzk_ctx* ctx, Fr* d_cols, size_t ncols, uint32_t n, size_t col_stride) {
+  return zk_sort_keys2(ctx, d_cols, ncols, nullptr, 0, n, col_stride);
 }
 
 // permute_expression_pair for L lookups: A (sorted inputs, in place), Ts (sorted tables), S out.
@@ -1057,8 +1079,7 @@ int zk_lookup_permute(amdzk_ctx* ctx, Fr* A, Fr* Ts, Fr* S, Fr* left, size_t L, 
   uint32_t* used = flags + L * flag_stride;
   uint32_t* rank_rep = flags + 2 * L * flag_stride;
   uint32_t* rank_left = flags + 3 * L * flag_stride;
-  ZK_TRY(zk_sort_keys(ctx, A, L, n, n));
-  if (tables_presorted < L) ZK_TRY(zk_sort_keys(ctx, Ts + tables_presorted * n, L - tables_presorted, n, n));
+  ZK_TRY(zk_sort_keys2(ctx, A, L, Ts + tables_presorted * n, L - tables_presorted, n, n));  // inputs and unsorted tables together
   ZK_HIP(ctx, hipMemsetAsync(flags, 0, 2 * L * flag_stride * sizeof(uint32_t), ctx->stream));
   dim3 grid((u + 255) / 256, (unsigned)L), block(256);
   ZK_LAUNCH(ctx, "lookup_mark", lookup_mark_kernel, grid, block, 0, A, Ts, (size_t)n, u, rep, used, flag_stride, d_err);
