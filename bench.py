@@ -126,6 +126,20 @@ def launch_ranks(n, argv, worker=None, env_extra=None, timeout=None):
     return rc
 
 
+def rank_core_slice(allowed, local_rank, local_world):
+    """The cores rank `local_rank` of `local_world` ranks on one host keeps: the r-th contiguous slice of the sorted ids
+    the launcher itself may use. Slices are disjoint and cover `allowed`; with fewer cores than ranks the ranks share
+    cores round-robin (a rank never ends up with an empty mask)."""
+    allowed = sorted(allowed)
+    n = len(allowed)
+    if local_world <= 1 or n == 0:
+        return allowed
+    if n < local_world:
+        return [allowed[local_rank % n]]
+    lo, hi = local_rank * n // local_world, (local_rank + 1) * n // local_world
+    return allowed[lo:hi]
+
+
 # ------------------------------------------------------------------------------------------ provers
 class DevView:
     def __init__(self, ptr):
@@ -332,9 +346,16 @@ def run_rank(args):
     # proofs in flight than queues, kernels of different proofs queue up behind each other. Must be set before the
     # runtime initialises (libamdzk.so's own initialiser does the same for hosts that load it first).
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-    cores_allowed = None
+    cores_allowed = core_slice = None
     if hasattr(os, "sched_getaffinity"):
-        if args.host_cores > 0:  # before torch / HIP: no exec, no taskset hop; threads started later inherit the mask
+        # before torch / HIP: no exec, no taskset hop; threads started later inherit the mask.
+        # N > 1 ranks on one host: rank r keeps the r-th slice of the cores the launcher was allowed (one host worker
+        # set per GPU) — otherwise N x (P + 1) driver threads and N OpenMP pools share one mask.
+        lw = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        if lw > 1 and os.environ.get("AMDZK_BENCH_NO_CORE_SLICE") != "1":
+            core_slice = rank_core_slice(sorted(os.sched_getaffinity(0)), int(os.environ.get("LOCAL_RANK", "0")), lw)
+            os.sched_setaffinity(0, core_slice)
+        if args.host_cores > 0:
             os.sched_setaffinity(0, sorted(os.sched_getaffinity(0))[:args.host_cores])
         cores_allowed = len(os.sched_getaffinity(0))
     import torch
@@ -384,7 +405,11 @@ def run_rank(args):
         witness_seeds = [s * world + rank for s in range(nw)]
     else:
         witness_seeds = [7 + 1000 * rank + j for j in range(nw)]
-    want_cpu = rank == 0 and not args.no_cpu_baseline and not stub
+    # the CPU baseline and the k = 22 stress belong to the N = 1 line only (rank 0 of N > 1 has 1/N of the host's cores,
+    # and the other ranks would sit in the closing barrier meanwhile)
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and not stub
+    if world > 1:
+        args.no_cpu_baseline = args.no_k22 = True
     prover = (StubProver if stub else GpuProver)(args, rank, local_rank, P, witness_seeds, want_cpu)
     desc = prover.desc
 
@@ -464,6 +489,15 @@ def run_rank(args):
         if not stream_equal:
             raise SystemExit("bench.py: proofs from streamed witnesses differ from the resident-witness proofs")
 
+    # host cores of every rank (count, first id, last id) for the line
+    my_mask = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
+    rank_cores = [[len(my_mask), my_mask[0] if my_mask else -1, my_mask[-1] if my_mask else -1]]
+    if dist_on and world > 1:
+        mine = torch.tensor(rank_cores[0], device=coll_dev, dtype=torch.int64)
+        allm = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allm, mine)
+        rank_cores = [[int(v) for v in t.cpu().tolist()] for t in allm]
+
     roof = cpu = None
     wall_prof = lat_ms = lat_serial_ms = k22 = None
     if rank == 0 and not stub:
@@ -507,6 +541,9 @@ def run_rank(args):
                            "timed_regions": len(regions),
                            "host_cpu_s_per_proof": round(host_cpu_s / steps, 5), "host_threads": min(P, steps) + 1,
                            "host_cores_allowed": cores_allowed,
+                           "host_cores_per_rank": [{"rank": r, "cores": c[0], "first": c[1], "last": c[2]} for r, c in enumerate(rank_cores)],
+                           "host_cores_rule": ("rank r keeps the r-th contiguous slice of the launcher's allowed cores (sched_setaffinity before "
+                                               "any GPU call)") if core_slice is not None else "the launcher's mask, unchanged",
                            "host_wait": "block (driver threads poll a completion event with 50-us sleeps)" if block_waits else "spin (hipStreamSynchronize)",
                            "host_note": "rank 0's process CPU time (all threads) over the median region / its proofs; one host thread "
                                         "per proof in flight, blocked in the HIP runtime while the GPU works",
@@ -751,8 +788,9 @@ def k22_stress(prover, want_cpu):
         vp = lambda arr: arr.ctypes.data_as(ctypes.c_void_p)
         scal = np.ascontiguousarray(uni.cpu().numpy().view(np.uint64))
         bases = params._g
-        kern = {"cores": th, "note": "liboracle.so (C++/OpenMP restatement of best_multiexp / best_fft), one run each, on the first 2^k "
-                                     "scalars and SRS points of the 2^22 stress inputs"}
+        kern = {"cores": th, "host_cores": PF.host_cores(),
+                "note": "liboracle.so (C++/OpenMP restatement of best_multiexp / best_fft), one run each, on the first 2^k "
+                        "scalars and SRS points of the 2^22 stress inputs; *_16_threads = the same on a 16-thread pool (rounds 1-3's figure)"}
         for kk in (15, 18, 22):
             m = 1 << kk
             res = np.zeros(8, np.uint64)
@@ -768,6 +806,15 @@ def k22_stress(prover, want_cpu):
             t0 = time.perf_counter()
             L.oracle_best_fft(vp(v), vp(w), ctypes.c_uint32(kk), ctypes.c_int(th))
             kern["ntt_2^%d_ms" % kk] = round((time.perf_counter() - t0) * 1e3, 2)
+            if th > 16:
+                res16 = np.zeros(8, np.uint64)
+                t0 = time.perf_counter()
+                L.oracle_best_multiexp(vp(scal), vp(bases), ctypes.c_size_t(m), ctypes.c_int(16), vp(res16))
+                kern["msm_2^%d_ms_16_threads" % kk] = round((time.perf_counter() - t0) * 1e3, 2)
+                v16 = np.ascontiguousarray(scal[:m].copy())
+                t0 = time.perf_counter()
+                L.oracle_best_fft(vp(v16), vp(w), ctypes.c_uint32(kk), ctypes.c_int(16))
+                kern["ntt_2^%d_ms_16_threads" % kk] = round((time.perf_counter() - t0) * 1e3, 2)
             if kk == k:
                 b = uni.clone()
                 pkg.arithmetic.best_fft_dev(ctx, V(b), w, k)
@@ -813,17 +860,34 @@ def cpu_baseline(prover, gpu_proof):
     t0 = time.perf_counter()
     fpk = PF.FastKey(c.desc, c.fixed, c.assembly.mapping, prover.s_int, prover.tr_int, msm_bases=(prover.params._g, prover.params._gl))
     t_keygen = time.perf_counter() - t0
+    hc = PF.host_cores()
     times, equal = [], True
-    for _ in range(2):  # two samples (~17 s of CPU work on the box's 16 threads): the first also warms the OpenMP pool
+    for _ in range(2):  # two samples on every usable core: the first also warms the OpenMP pool
         t0 = time.perf_counter()
         proof = PF.create_proof(fpk, instances, advice, seed=424242)
         times.append(time.perf_counter() - t0)
         equal = equal and proof == gpu_proof
     dt = min(times)
-    return {"value": round(1.0 / dt, 5), "unit": "proofs/s", "cores": PF.threads(), "kind": "port",
-            "sample": "2 full create_proof runs (same circuit/witness/SRS/seed as the GPU run) with the C++/OpenMP oracle prover, "
-                      "%d threads, the faster one reported; Python transcript/RNG/glue included; keygen (%.0f s) excluded" % (PF.threads(), t_keygen),
-            "seconds_per_proof": round(dt, 2), "seconds_per_proof_samples": [round(t, 2) for t in times], "proof_bytes_equal_gpu": equal}
+    th = PF.threads()
+    out = {"value": round(1.0 / dt, 5), "unit": "proofs/s", "cores": th, "kind": "port",
+           "sample": "2 full create_proof runs (same circuit/witness/SRS/seed as the GPU run) with the C++/OpenMP oracle prover on "
+                     "%d threads = every core this process may use (affinity mask %d cores, cgroup cpu.max %r), the faster one reported; "
+                     "Python transcript/RNG/glue included; keygen (%.0f s) excluded"
+                     % (th, hc["affinity_cores"], hc["cgroup_cpu_max"], t_keygen),
+           "seconds_per_proof": round(dt, 2), "seconds_per_proof_samples": [round(t, 2) for t in times],
+           "host_cores": hc}
+    if th > 16 and not os.environ.get("ORACLE_THREADS"):
+        # the figure of rounds 1-3 (a 16-thread pool) beside it: one more sample
+        PF.set_threads(16)
+        try:
+            t0 = time.perf_counter()
+            proof = PF.create_proof(fpk, instances, advice, seed=424242)
+            out["seconds_per_proof_16_threads"] = round(time.perf_counter() - t0, 2)
+            equal = equal and proof == gpu_proof
+        finally:
+            PF.set_threads(None)
+    out["proof_bytes_equal_gpu"] = equal
+    return out
 
 
 def main(argv=None):

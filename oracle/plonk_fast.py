@@ -38,9 +38,52 @@ def lib():
     return _L
 
 
-def threads():
+def cgroup_cpu_quota():
+    """(text, cores): the CPU bandwidth limit of this process's cgroup — cgroup v2 `cpu.max` ("max 100000" = none) or
+    v1 `cpu.cfs_quota_us` / `cpu.cfs_period_us` — as read, and as a number of cores (None = no limit)."""
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            txt = open(path).read().strip()
+            q, per = txt.split()[:2]
+            return txt, (None if q == "max" else float(q) / float(per))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return "%d %d" % (q, per), (None if q <= 0 else q / per)
+    except (OSError, ValueError):
+        return None, None
+
+
+def host_cores():
+    """What the CPU baseline may use: the cores of this process's affinity mask, bounded by its cgroup's CPU quota if
+    it has one (threads beyond a quota are throttled, not run). rayon's default pool — what upstream's create_proof
+    would use (/root/reference/Cargo.lock:890) — is the affinity count; the quota bound keeps the figure honest on a
+    box that hands out a share of a larger host."""
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    return max(1, min(lib().oracle_max_threads(), avail, int(os.environ.get("ORACLE_THREADS", "16"))))
+    txt, quota = cgroup_cpu_quota()
+    use = avail if quota is None else max(1, min(avail, int(quota + 0.999)))
+    return {"affinity_cores": avail, "cgroup_cpu_max": txt, "cgroup_quota_cores": quota, "usable_cores": use}
+
+
+_THREADS = None
+
+
+def set_threads(n):
+    """Override the thread count of every OpenMP loop of this module (None = back to the default rule)."""
+    global _THREADS
+    _THREADS = None if n is None else max(1, int(n))
+
+
+def threads():
+    """OpenMP threads of the oracle's loops: set_threads() > ORACLE_THREADS > all usable host cores (host_cores())."""
+    if _THREADS is not None:
+        return _THREADS
+    env = os.environ.get("ORACLE_THREADS")
+    if env:
+        return max(1, int(env))
+    return max(1, host_cores()["usable_cores"])
 
 
 def _p(a):

@@ -115,3 +115,30 @@ def test_issue_bound_model_and_stamped_summary():
         assert 0.5 < got["mad_share"] < 0.9 and got["valu"] > 1e8
     else:
         assert got["source"].startswith("none for kernel sources")
+
+
+def test_ranks_get_disjoint_core_slices():
+    """N ranks on one host: rank r keeps the r-th contiguous slice of the launcher's allowed cores. The pure
+    rule first, then the real launcher with the stub: the masks the ranks report are disjoint whenever the launcher
+    has at least one core per rank."""
+    import bench
+    for n, w in ((256, 8), (16, 8), (8, 8), (10, 4), (64, 3)):
+        sl = [bench.rank_core_slice(range(n), r, w) for r in range(w)]
+        flat = [c for s_ in sl for c in s_]
+        assert sorted(flat) == list(range(n)) and len(set(flat)) == n, "slices must partition the mask"
+        assert max(len(s_) for s_ in sl) - min(len(s_) for s_ in sl) <= 1
+    assert [bench.rank_core_slice(range(3), r, 8) for r in range(8)] == [[0], [1], [2], [0], [1], [2], [0], [1]]
+    assert bench.rank_core_slice([5, 2, 9], 0, 1) == [2, 5, 9]
+    avail = sorted(os.sched_getaffinity(0))
+    ranks = 2 if len(avail) < 8 else 8
+    r = run_bench(["--gpus", str(ranks), "--steps", "2", "--warmup", "0", "--regions", "1"], {"AMDZK_BENCH_STUB": "1"}, timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ln = json_lines(r.stdout)[0]
+    per = ln["config"]["host_cores_per_rank"]
+    assert [p["rank"] for p in per] == list(range(ranks))
+    if len(avail) >= ranks:
+        spans = sorted((p["first"], p["last"]) for p in per)
+        assert all(a[1] < b[0] for a, b in zip(spans, spans[1:])), "core slices of the ranks overlap: %r" % per
+        assert sum(p["cores"] for p in per) == len(avail)
+        assert ln["config"]["host_cores_allowed"] == per[0]["cores"]
+    assert "slice" in ln["config"]["host_cores_rule"]

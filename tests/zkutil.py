@@ -3,6 +3,7 @@ The oracle is test infrastructure; nothing under anon-aadhaar-halo2_amd/ imports
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -96,10 +97,10 @@ class Oracle:
             subprocess.check_call(["make"], cwd=os.path.join(ROOT, "oracle"))
         self.L = C.CDLL(path)
         self.L.oracle_max_threads.restype = C.c_int
-        # A one-GPU box gives this job a 16-core share of the host (the pool's rule), whatever
-        # omp_get_max_threads() reports; oversubscribing it only adds noise.
-        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        self.threads = max(1, min(self.L.oracle_max_threads(), avail, int(os.environ.get("ORACLE_THREADS", "16"))))
+        # ORACLE_THREADS, else every core this process may use (affinity mask bounded by the cgroup quota: plonk_fast.host_cores)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import plonk_fast as _pf
+        self.threads = _pf.threads()
 
     def _bin(self, fn, a, b):
         a, b = np.ascontiguousarray(a, np.uint64), np.ascontiguousarray(b, np.uint64)
