@@ -9,7 +9,7 @@ and a gfx950 device and raises otherwise. The directory name contains a hyphen (
 repository's name); import it with `__graft_entry__.load_package()` which registers it as
 `anon_aadhaar_halo2_amd`.
 """
-from .ffi import AmdzkError, Context, lib, lib_path  # noqa: F401
+from .ffi import AmdzkError, Context, build_info, lib, lib_path  # noqa: F401
 from . import batch  # noqa: F401
 from .halo2 import arithmetic, domain, kzg, plonk  # noqa: F401
 from . import feeder, workloads  # noqa: F401

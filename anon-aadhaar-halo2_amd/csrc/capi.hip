@@ -7,6 +7,7 @@
 #include <atomic>
 
 #include "common.hpp"
+#include "build_stamp.h"  // AMDZK_SRC_HASH: written by the Makefile from the kernel sources (tools/src_hash.py)
 
 using namespace bn254;
 
@@ -112,6 +113,7 @@ int zk_ptr_on_device(amdzk_ctx* ctx, const void* p, const char* what) {
 // Also measured and rejected: keeping the lanes' streams off every 2nd / 4th / 8th compute unit (a CU mask,
 // hipExtStreamCreateWithCUMask) so that the caller's stream always finds free compute units: 19.8-19.95 ms per proof
 // against 19.35 without (profiles/r03e_host_wait_and_cu_mask.txt).
+void zk_note_streams(int delta);
 hipError_t zk_stream_create(hipStream_t* s, bool /*lane*/) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
 
 int zk_lane(amdzk_ctx* ctx, int i, amdzk_ctx** out) {
@@ -131,23 +133,30 @@ int zk_lane(amdzk_ctx* ctx, int i, amdzk_ctx** out) {
     }
     l->stream = l->own_stream;
     ctx->lanes[i] = l;
+    zk_note_streams(1);
   }
   *out = ctx->lanes[i];
   return AMDZK_OK;
 }
 
+// Failures of the ordering calls are reported on the ROOT context (the one the caller holds and asks amdzk_last_error
+// about), whichever lane waits.
 int zk_stream_after(amdzk_ctx* waiter, amdzk_ctx* signaler) {
   if (waiter == signaler || waiter->stream == signaler->stream) return AMDZK_OK;
+  amdzk_ctx* rep = waiter->parent ? waiter->parent : waiter;
   hipEvent_t& e = signaler->order_evt[signaler->order_next++ % 8];
-  if (!e) ZK_HIP(waiter, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  ZK_HIP(waiter, hipEventRecord(e, signaler->stream));
-  ZK_HIP(waiter, hipStreamWaitEvent(waiter->stream, e, 0));
+  if (!e) ZK_HIP(rep, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  ZK_HIP(rep, hipEventRecord(e, signaler->stream));
+  ZK_HIP(rep, hipStreamWaitEvent(waiter->stream, e, 0));
   return AMDZK_OK;
 }
 
 int zk_stream_after_l1(amdzk_ctx* waiter, amdzk_ctx* signaler) {
-  if (waiter == signaler || waiter->stream == signaler->stream || !signaler->msm_l1_evt) return AMDZK_OK;
-  ZK_HIP(waiter, hipStreamWaitEvent(waiter->stream, signaler->msm_l1_evt, 0));
+  if (waiter == signaler || waiter->stream == signaler->stream) return AMDZK_OK;
+  if (!signaler->msm_l1_evt || !signaler->msm_l1_fresh) return zk_stream_after(waiter, signaler);
+  amdzk_ctx* rep = waiter->parent ? waiter->parent : waiter;
+  signaler->msm_l1_fresh = false;
+  ZK_HIP(rep, hipStreamWaitEvent(waiter->stream, signaler->msm_l1_evt, 0));
   return AMDZK_OK;
 }
 
@@ -176,19 +185,19 @@ static void ctx_release(amdzk_ctx* ctx) {
   for (auto e : ctx->msm_evt)
     if (e) hipEventDestroy(e);
   if (ctx->msm_l1_evt) hipEventDestroy(ctx->msm_l1_evt);
-  if (ctx->wait_evt) hipEventDestroy(ctx->wait_evt);
   if (ctx->msm_stream) {
-    hipStreamSynchronize(ctx->msm_stream);
+    zk_host_wait(ctx, ctx->msm_stream);
     hipStreamDestroy(ctx->msm_stream);
   }
   if (ctx->t0) hipEventDestroy(ctx->t0);
   if (ctx->t1) hipEventDestroy(ctx->t1);
   if (ctx->copy_stream) {
-    hipStreamSynchronize(ctx->copy_stream);
+    zk_host_wait(ctx, ctx->copy_stream);
     hipStreamDestroy(ctx->copy_stream);
   }
   if (ctx->copy_evt) hipEventDestroy(ctx->copy_evt);
   if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+  if (ctx->wait_evt) hipEventDestroy(ctx->wait_evt);
   delete ctx;
 }
 
@@ -203,25 +212,35 @@ struct HwQueuesDefault {
 } hw_queues_default;
 }  // namespace
 
-// Contexts alive in this process, against the hardware queues the HIP runtime was (most likely) initialised with: more
-// proofs in flight than queues queue up behind each other silently (6-9 % fewer proofs per second with 8-12 in flight on
-// the default 4), e.g. when the host initialised HIP before this library could set the variable. Said once, on stderr.
-static std::atomic<int> g_live_contexts{0};
+// Streams this library keeps busy in this process — one per context, two more per context whose proofs run on lanes
+// (default keys; AMDZK_KEYGEN_SERIAL keys stay on the context's stream) — against the hardware queues the HIP runtime
+// was (most likely) initialised with: more busy streams than queues queue up behind each other silently (6-9 % fewer
+// proofs per second with 8-12 proofs in flight on the default 4), e.g. when the host initialised HIP before this library
+// could set the variable. Said once, on stderr.
+static std::atomic<int> g_live_streams{0};
 static std::atomic<bool> g_queue_note_given{false};
-static void note_context_created() {
+void zk_note_streams(int delta) {
+  const int live = (g_live_streams += delta);
+  if (delta <= 0) return;
   const char* e = getenv("GPU_MAX_HW_QUEUES");
   const int queues = e && atoi(e) > 0 ? atoi(e) : 4;
-  const int live = ++g_live_contexts;
   if (live > queues && !g_queue_note_given.exchange(true))
     fprintf(stderr,
-            "[amdzk] note: %d contexts in this process but GPU_MAX_HW_QUEUES=%d hardware queues: kernels of different contexts will wait "
-            "for each other. Export GPU_MAX_HW_QUEUES >= the number of proofs in flight before the process's first HIP call.\n",
+            "[amdzk] note: %d streams of this library in this process (one per context, two more per context that proves on lanes) but "
+            "GPU_MAX_HW_QUEUES=%d hardware queues: kernels of different streams will wait for each other. Export GPU_MAX_HW_QUEUES >= the "
+            "number of proofs in flight before the process's first HIP call, and with 4 or more proofs in flight make the keys with "
+            "AMDZK_KEYGEN_SERIAL (one stream per proof; the proofs fill the chip between them).\n",
             live, queues);
 }
+static std::atomic<bool> g_blocking_note_given{false};
 
 extern "C" {
 
-int amdzk_version(void) { return 1000; }
+int amdzk_version(void) { return 1001; }
+
+// "amdzk <abi> src=<hash of the comment-stripped kernel sources and the Makefile> arch=gfx950": what this binary was built
+// from. bench.py refuses a library whose stamp is not its tree's bench.kernel_src_hash().
+const char* amdzk_build_info(void) { return "amdzk 1001 src=" AMDZK_SRC_HASH " arch=gfx950"; }
 
 int amdzk_init(int device_id, amdzk_ctx** out) {
   if (!out) return AMDZK_E_INVALID;
@@ -246,9 +265,22 @@ int amdzk_init(int device_id, amdzk_ctx** out) {
   }
   c->stream = c->own_stream;
   if (const char* e = getenv("AMDZK_HOST_WAIT")) c->host_wait_block = strcmp(e, "block") == 0;
+  // A host that runs this device with hipDeviceScheduleBlockingSync: the runtime's own waits (hipStreamSynchronize from
+  // one driver thread per proof in flight, on streams that share hardware queues) are the path that did not come back in
+  // round 3's experiment, so this library then polls on every host wait and never enters them.
+  unsigned dflags = 0;
+  // (hip_runtime_api.h: "on ROCm, hipDeviceScheduleBlockingSync is a synonym for hipDeviceScheduleYield" — both select the
+  // runtime's non-spinning wait, so both are treated alike.)
+  if (hipGetDeviceFlags(&dflags) == hipSuccess &&
+      ((dflags & hipDeviceScheduleMask) == hipDeviceScheduleBlockingSync || (dflags & hipDeviceScheduleMask) == hipDeviceScheduleYield)) {
+    c->wait_forced = true;
+    if (!g_blocking_note_given.exchange(true))
+      fprintf(stderr, "[amdzk] note: the device runs with hipDeviceScheduleBlockingSync / Yield: every host wait of this library polls a "
+                      "completion event (50-us sleeps) instead of calling the runtime's blocking waits.\n");
+  }
   hipEventCreate(&c->t0);
   hipEventCreate(&c->t1);
-  note_context_created();
+  zk_note_streams(1);
   *out = c;
   return AMDZK_OK;
 }
@@ -259,10 +291,11 @@ void amdzk_destroy(amdzk_ctx* ctx) {
   for (amdzk_ctx*& l : ctx->lanes)
     if (l) {
       ctx_release(l);
+      zk_note_streams(-1);
       l = nullptr;
     }
   ctx_release(ctx);
-  --g_live_contexts;
+  zk_note_streams(-1);
 }
 
 const char* amdzk_last_error(const amdzk_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
@@ -278,7 +311,7 @@ int amdzk_set_stream(amdzk_ctx* ctx, void* hip_stream) {
 int amdzk_set_host_wait(amdzk_ctx* ctx, int mode) {
   if (!ctx) return AMDZK_E_INVALID;
   if (mode != AMDZK_WAIT_SPIN && mode != AMDZK_WAIT_BLOCK) ZK_FAIL(ctx, AMDZK_E_INVALID, "set_host_wait: unknown mode %d", mode);
-  ctx->host_wait_block = mode == AMDZK_WAIT_BLOCK;
+  ctx->host_wait_block = mode == AMDZK_WAIT_BLOCK;  // (with wait_forced the waits poll either way)
   return AMDZK_OK;
 }
 
@@ -329,7 +362,7 @@ int amdzk_host_free(amdzk_ctx* ctx, void* hptr) {
   ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
   if (!hptr) return AMDZK_OK;
-  if (ctx->copy_stream) ZK_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));
+  if (ctx->copy_stream) ZK_HIP(ctx, zk_host_wait(ctx, ctx->copy_stream));
   ZK_HIP(ctx, hipHostFree(hptr));
   return AMDZK_OK;
 }
@@ -527,7 +560,7 @@ int amdzk_timer_stop(amdzk_ctx* ctx, float* ms) {
   ZK_ENTER(ctx);
   if (!ctx || !ms) return AMDZK_E_INVALID;
   ZK_HIP(ctx, hipEventRecord(ctx->t1, ctx->stream));
-  ZK_HIP(ctx, hipEventSynchronize(ctx->t1));
+  ZK_HIP(ctx, zk_host_wait_event(ctx, ctx->t1));
   ZK_HIP(ctx, hipEventElapsedTime(ms, ctx->t0, ctx->t1));
   return AMDZK_OK;
 }

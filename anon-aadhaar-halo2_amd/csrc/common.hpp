@@ -66,9 +66,14 @@ struct amdzk_ctx {
   size_t h_pinned_cap = 0;
 
   // How the host waits for the device (zk_host_wait): spinning in hipStreamSynchronize — lowest latency, one busy core
-  // per waiting thread — or sleeping on a blocking-sync event — the thread leaves its core to the other proofs' drivers.
-  // amdzk_set_host_wait / AMDZK_HOST_WAIT=block; lanes follow their parent.
+  // per waiting thread — or POLLING a completion event (hipEventQuery, a few microseconds of yielding, then 50-us
+  // sleeps) — the thread leaves its core to the other proofs' drivers; each wait then ends up to one sleep quantum late.
+  // amdzk_set_host_wait / AMDZK_HOST_WAIT=block; lanes follow their parent. wait_forced: the host process runs the device
+  // with hipDeviceScheduleBlockingSync (read in amdzk_init); this library then never calls a blocking wait of the runtime
+  // — every host wait polls, whatever amdzk_set_host_wait says (profiles/r03e_host_wait_and_cu_mask.txt: under that flag
+  // ten driver threads in hipStreamSynchronize did not finish a 20-proof bench in 300 s).
   bool host_wait_block = false;
+  bool wait_forced = false;
   hipEvent_t wait_evt = nullptr;
 
   // Lanes: auxiliary contexts on the same device (own stream, workspaces, staging) for work of ONE call that is
@@ -89,6 +94,7 @@ struct amdzk_ctx {
   // would only compete with that chip-filling kernel waits for it (zk_stream_after_l1) and then runs beside the batch's
   // latency-bound tail instead
   hipEvent_t msm_l1_evt = nullptr;
+  bool msm_l1_fresh = false;  // a batch recorded msm_l1_evt and nothing has waited for it yet (zk_stream_after_l1 consumes it)
 };
 
 #define ZK_FAIL(ctx, code, ...)                         \
@@ -143,17 +149,12 @@ struct ZkDeviceGuard {
 // POLLED — a few microseconds of yielding, then 50-microsecond sleeps — so that a waiting thread leaves its core to
 // the threads that have kernels to launch. (The runtime's own blocking waits are not usable here: events created with
 // hipEventBlockingSync still spin in hipEventSynchronize on this ROCm, and the device-wide
-// hipDeviceScheduleBlockingSync flag stalled the ten-proofs-in-flight bench outright — measured, round 3.)
-inline hipError_t zk_host_wait(amdzk_ctx* ctx, hipStream_t s) {
-  const amdzk_ctx* root = ctx->parent ? ctx->parent : ctx;
-  if (!root->host_wait_block) return hipStreamSynchronize(s);
-  hipError_t e = hipSuccess;
-  if (!ctx->wait_evt) e = hipEventCreateWithFlags(&ctx->wait_evt, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventRecord(ctx->wait_evt, s);
-  if (e != hipSuccess) return e;
+// hipDeviceScheduleBlockingSync flag stalled the ten-proofs-in-flight bench outright — measured, round 3. A host that
+// sets that flag itself is detected in amdzk_init and gets polling waits throughout: amdzk_ctx::wait_forced.)
+inline hipError_t zk_event_poll(hipEvent_t evt) {
   const auto t0 = std::chrono::steady_clock::now();
   for (;;) {
-    e = hipEventQuery(ctx->wait_evt);
+    hipError_t e = hipEventQuery(evt);
     if (e != hipErrorNotReady) return e;
     if (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(20)) {
       std::this_thread::yield();
@@ -162,6 +163,20 @@ inline hipError_t zk_host_wait(amdzk_ctx* ctx, hipStream_t s) {
     }
   }
 }
+inline bool zk_waits_poll(const amdzk_ctx* ctx) {
+  const amdzk_ctx* root = ctx->parent ? ctx->parent : ctx;
+  return root->host_wait_block || root->wait_forced;
+}
+inline hipError_t zk_host_wait(amdzk_ctx* ctx, hipStream_t s) {
+  if (!zk_waits_poll(ctx)) return hipStreamSynchronize(s);
+  hipError_t e = hipSuccess;
+  if (!ctx->wait_evt) e = hipEventCreateWithFlags(&ctx->wait_evt, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventRecord(ctx->wait_evt, s);
+  if (e != hipSuccess) return e;
+  return zk_event_poll(ctx->wait_evt);
+}
+// Host waits for an event already recorded (the timer's stop event).
+inline hipError_t zk_host_wait_event(amdzk_ctx* ctx, hipEvent_t evt) { return zk_waits_poll(ctx) ? zk_event_poll(evt) : hipEventSynchronize(evt); }
 
 int zk_ws_reserve(amdzk_ctx* ctx, int slot, size_t bytes, void** out);
 int zk_pinned_reserve(amdzk_ctx* ctx, size_t bytes, void** out);
@@ -174,7 +189,9 @@ hipError_t zk_stream_create(hipStream_t* s, bool low_priority);
 // Everything enqueued on `waiter`'s stream after this call runs after everything enqueued on `signaler`'s stream
 // before it (event record + stream wait; no host synchronisation). No-op when both are the same context.
 int zk_stream_after(amdzk_ctx* waiter, amdzk_ctx* signaler);
-// Everything enqueued on `waiter` after this call runs after the level-1 kernel of the last commitment batch launched on `signaler`.
+// Everything enqueued on `waiter` after this call runs after the level-1 kernel of the last commitment batch launched on
+// `signaler` — or, when no batch has recorded that event since the last call (no columns, nothing launched), after
+// everything enqueued on `signaler` (zk_stream_after): never a stale event, never no ordering at all.
 int zk_stream_after_l1(amdzk_ctx* waiter, amdzk_ctx* signaler);
 // Host waits for the ctx's stream and all its lanes.
 int zk_sync_all(amdzk_ctx* ctx);

@@ -155,21 +155,27 @@ struct DigitArgs {
 // One workgroup owns `chunk` consecutive scalars of one column. Counting and cursor bumping happen in
 // LDS (ds_add / ds_add_rtn), so global memory sees one coalesced histogram write per workgroup
 // instead of one atomic per digit.
-template <int C, bool SCATTER>
-__global__ __launch_bounds__(MSM_THREADS) void msm_digit_kernel(DigitArgs a) {
+// BIG: 1024 threads per workgroup instead of 256 — for the few-columns / long-column case (k >= 19: one 2^22-point
+// column is 64 workgroups of 256 threads otherwise, a quarter of the chip's SIMDs with one wavefront each, every thread a
+// dependent chain of load -> Montgomery reduction -> 16 LDS atomics -> 16 scattered stores: 1.96 + 0.43 ms of the 9.9 ms
+// of a 2^22-point MSM, profiles/r04a_*). The counters of a workgroup fill LDS (2^15 buckets = 128 KiB), so a compute unit
+// holds one workgroup whatever its size: sixteen wavefronts hide that chain where four do not.
+template <int C, bool SCATTER, bool BIG>
+__global__ __launch_bounds__(BIG ? 1024 : MSM_THREADS) void msm_digit_kernel(DigitArgs a) {
   extern __shared__ uint32_t lds_cnt[];  // nb counters / cursors
+  constexpr uint32_t THREADS = BIG ? 1024 : MSM_THREADS;
   const uint32_t col = blockIdx.y, blk = blockIdx.x, t = threadIdx.x;
   uint32_t* gh = a.blk_hist + ((size_t)col * a.nblk + blk) * a.nb;
   if (!SCATTER) {
-    for (uint32_t b = t; b < a.nb; b += MSM_THREADS) lds_cnt[b] = 0;
+    for (uint32_t b = t; b < a.nb; b += THREADS) lds_cnt[b] = 0;
   } else {
     const uint32_t* off = a.off0 + (size_t)col * (a.nb + 1);
-    for (uint32_t b = t; b < a.nb; b += MSM_THREADS) lds_cnt[b] = off[b] + gh[b];
+    for (uint32_t b = t; b < a.nb; b += THREADS) lds_cnt[b] = off[b] + gh[b];
   }
   __syncthreads();
   const uint32_t lo_i = blk * a.chunk, hi_i = min(lo_i + a.chunk, a.len);
   uint32_t* ent = a.entries + (size_t)col * a.ecap;
-  for (uint32_t i = lo_i + t; i < hi_i; i += MSM_THREADS) {
+  for (uint32_t i = lo_i + t; i < hi_i; i += THREADS) {
     const uint4* sp = reinterpret_cast<const uint4*>(a.scalars + (size_t)col * a.col_stride + i);
     uint4 lo = sp[0], hi = sp[1];
     if ((lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) == 0) continue;
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_digit_kernel(DigitArgs a) {
   }
   if (!SCATTER) {
     __syncthreads();
-    for (uint32_t b = t; b < a.nb; b += MSM_THREADS) gh[b] = lds_cnt[b];
+    for (uint32_t b = t; b < a.nb; b += THREADS) gh[b] = lds_cnt[b];
   }
 }
 
@@ -214,8 +220,8 @@ __global__ __launch_bounds__(256) void msm_blk_offsets_kernel(uint32_t* blk_hist
 //   mode 2: v[b] = number of T-aligned chunks of the whole list that intersect [src[b], src[b+1])
 __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* src, uint32_t* off_out,
                                                          uint32_t nb, uint32_t T, int src_is_hist) {
-  __shared__ uint32_t part[1024];
-  const uint32_t col = blockIdx.x, t = threadIdx.x;
+  __shared__ uint32_t wtot[16];
+  const uint32_t col = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const uint32_t* s = src + (size_t)col * (src_is_hist == 1 ? nb : nb + 1);
   uint32_t* o = off_out + (size_t)col * (nb + 1);
   const uint32_t per = (nb + 1023) / 1024;
@@ -227,20 +233,33 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* src, uin
   };
   uint32_t sum = 0;
   for (uint32_t b = b0; b < b1; b++) sum += val(b);
-  part[t] = sum;
-  __syncthreads();
-  for (uint32_t d = 1; d < 1024; d <<= 1) {  // Hillis-Steele inclusive scan
-    uint32_t v = t >= d ? part[t - d] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
+  // inclusive scan of the 1024 thread sums: shuffles inside a wavefront, the 16 wavefront totals through LDS (two
+  // barriers; the Hillis-Steele scan over LDS this replaces took twenty, and the kernel is pure latency: four or five
+  // launches of one workgroup per column on the chain of every commitment batch)
+  uint32_t inc = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t v = __shfl_up(inc, d, 64);
+    if ((int)lane >= d) inc += v;
   }
-  uint32_t run = part[t] - sum;
+  if (lane == 63) wtot[wv] = inc;
+  __syncthreads();
+  if (wv == 0) {
+    uint32_t w = lane < 16 ? wtot[lane] : 0u;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      const uint32_t v = __shfl_up(w, d, 64);
+      if ((int)lane >= d) w += v;
+    }
+    if (lane < 16) wtot[lane] = w;  // inclusive totals
+  }
+  __syncthreads();
+  uint32_t run = inc - sum + (wv ? wtot[wv - 1] : 0u);
   for (uint32_t b = b0; b < b1; b++) {
     o[b] = run;
     run += val(b);
   }
-  if (t == 1023) o[nb] = part[1023];
+  if (t == 1023) o[nb] = wtot[15];
 }
 
 // ------------------------------------------------------------------ accumulation levels
@@ -382,6 +401,20 @@ __device__ __forceinline__ G1X29 wave_suffix29(G1X29 v, uint32_t lane) {
   }
   return v;
 }
+// The same over the first `n` lanes only (n a power of two <= 64; the other lanes must hold the identity).
+__device__ __forceinline__ G1X29 wave_sum29_n(G1X29 v, int n) {
+#pragma unroll 1
+  for (int m = n >> 1; m >= 1; m >>= 1) v = x29_add(v, shfl_xor_x29(v, m));
+  return v;
+}
+__device__ __forceinline__ G1X29 wave_suffix29_n(G1X29 v, uint32_t lane, int n) {
+#pragma unroll 1
+  for (int d = 1; d < n; d <<= 1) {
+    const G1X29 o = shfl_down_x29(v, d);
+    v = x29_add(v, (int)lane + d < n ? o : G1X29::inf());
+  }
+  return v;
+}
 // The 32-bit flavour, for the start-up-only group FFT below.
 __device__ __forceinline__ Fq shfl_xor_fq(const Fq& v, int m) {
   Fq r;
@@ -427,18 +460,23 @@ __global__ __launch_bounds__(64) void msm_accum_final_kernel(const uint32_t* off
 // transcript's chain at the end of every commitment batch, so what counts is its DEPTH: 8 + 3 additions with eight
 // wavefronts (round 3) against 16 + 3 with four.
 constexpr uint32_t ROWCOL_WAVES = 8;
+// Units [0, U) with U = ceil(G / 64): the column sums over the row groups g in [64 u, 64 u + 64) (lane = r; cols[col][u][r] —
+// msm_fold adds the U slices: one slice up to k = 18, eight at k = 22, where ONE unit summing all 512 row groups was a
+// chain of 64 + 3 additions, 0.7 ms of a 2^22-point MSM); units [U, 2U): the row sums of g in [64 (unit - U), ...) (lane = g).
 __global__ __launch_bounds__(64 * ROWCOL_WAVES) void msm_rowcol_kernel(const G1X29* dense, uint32_t nb, G1X29* rows, G1X29* cols) {
   __shared__ G1X29 part[ROWCOL_WAVES / 2][64];
-  const uint32_t col = blockIdx.y, unit = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint32_t G = nb >> 6;
+  const uint32_t col = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t G = nb >> 6, U = (G + 63) >> 6;
+  const bool col_unit = blockIdx.x < U;
+  const uint32_t unit = col_unit ? blockIdx.x : blockIdx.x - U;
   const G1X29* d = dense + (size_t)col * nb;
-  const uint32_t g_row = (unit - 1) * 64 + lane;  // unit >= 1 only
+  const uint32_t g_row = unit * 64 + lane;  // row units only
+  constexpr uint32_t per = 64 / ROWCOL_WAVES;
   G1X29 acc = G1X29::inf();
-  if (unit == 0) {
-    const uint32_t per = (G + ROWCOL_WAVES - 1) / ROWCOL_WAVES, g0 = wv * per, g1 = min(G, g0 + per);
+  if (col_unit) {
+    const uint32_t g0 = unit * 64 + per * wv, g1 = min(G, g0 + per);
     for (uint32_t g = g0; g < g1; g++) acc = x29_add(acc, ld_x29(d + 64 * g + lane));
   } else if (g_row < G) {
-    constexpr uint32_t per = 64 / ROWCOL_WAVES;
     for (uint32_t r = per * wv; r < per * wv + per; r++) acc = x29_add(acc, ld_x29(d + 64 * g_row + r));
   }
   for (uint32_t half = ROWCOL_WAVES / 2; half >= 1; half >>= 1) {  // waves [half, 2 half) hand their sums to waves [0, half)
@@ -448,7 +486,7 @@ __global__ __launch_bounds__(64 * ROWCOL_WAVES) void msm_rowcol_kernel(const G1X
     __syncthreads();
   }
   if (wv == 0) {
-    if (unit == 0) st_x29(cols + (size_t)col * 64 + lane, acc);
+    if (col_unit) st_x29(cols + ((size_t)col * U + unit) * 64 + lane, acc);
     else if (g_row < G) st_x29(rows + (size_t)col * G + g_row, acc);
   }
 }
@@ -493,7 +531,8 @@ __global__ __launch_bounds__(576) void msm_fold_kernel(const G1X29* rows, const 
       const uint32_t g = wv * 64 + lane;
       v = g < G ? ld_x29(rows + (size_t)col * G + g) : G1X29::inf();
     } else {
-      v = ld_x29(cols + (size_t)col * 64 + lane);
+      v = ld_x29(cols + (size_t)col * W * 64 + lane);  // the W slices of the column sums (msm_rowcol)
+      for (uint32_t u = 1; u < W; u++) v = x29_add(v, ld_x29(cols + ((size_t)col * W + u) * 64 + lane));
     }
     const G1X29 suf = wave_suffix29(v, lane);
     if (lane == 0 && wv < W) partB[wv] = suf;
@@ -504,27 +543,27 @@ __global__ __launch_bounds__(576) void msm_fold_kernel(const G1X29* rows, const 
     }
   }
   __syncthreads();
-  if (t == 0) {
+  if (wv == 0) {
     G1X29 sum_b = partB[0], acc = partA[0];
     if (W > 1) {
-      // Y = sum_w w B_w = the sum of the suffix sums of B over w = 1 .. W - 1; then acc = 64 Y + sum_w A_w
-      G1X29 suf = partB[W - 1], y = partB[W - 1];
-      for (uint32_t w = W - 2; w >= 1; w--) {
-        suf = x29_add(suf, partB[w]);
-        y = x29_add(y, suf);
-      }
+      // wavefront 0, lanes w < W (<= 8): acc = sum_w A_w, sum_b = sum_w B_w, and Y = sum_w w B_w = the sum of the suffix
+      // sums of B over w = 1 .. W - 1 — three shuffle rounds each instead of lane 0 walking the W values three times
+      const G1X29 a = lane < W ? partA[lane] : G1X29::inf();
+      const G1X29 b = lane < W ? partB[lane] : G1X29::inf();
+      const G1X29 sufb = wave_suffix29_n(b, lane, 8);
+      acc = wave_sum29_n(a, 8);
+      G1X29 y = wave_sum29_n(lane == 0 || lane >= W ? G1X29::inf() : sufb, 8);
+      sum_b = sufb;  // lane 0: the plain sum
 #pragma unroll 1
       for (int i = 0; i < 6; i++) y = x29_dbl(y);
-      for (uint32_t w = 1; w < W; w++) {
-        acc = x29_add(acc, partA[w]);
-        sum_b = x29_add(sum_b, partB[w]);
-      }
       acc = x29_add(acc, y);
     }
+    if (t == 0) {
 #pragma unroll 1
-    for (int i = 0; i < 6; i++) acc = x29_dbl(acc);
-    acc = x29_add(acc, sum_b);
-    st_x(out + col, x29_to_r256(x29_add(acc, partC)));
+      for (int i = 0; i < 6; i++) acc = x29_dbl(acc);
+      acc = x29_add(acc, sum_b);
+      st_x(out + col, x29_to_r256(x29_add(acc, partC)));
+    }
   }
 }
 
@@ -546,19 +585,28 @@ uint32_t pick_window_bits(uint32_t k) {
 }
 
 template <bool SCATTER>
-int launch_digits(amdzk_ctx* ctx, uint32_t c, const DigitArgs& a, dim3 grid) {
-  dim3 block(MSM_THREADS);
+int launch_digits(amdzk_ctx* ctx, uint32_t c, const DigitArgs& a, dim3 grid, bool big) {
   const size_t shmem = (size_t)a.nb * sizeof(uint32_t);
   const char* nm = SCATTER ? "msm_scatter" : "msm_hist";
   switch (c) {
-#define ZK_CASE(CC)                                                \
-  case CC: {                                                       \
-    auto kfn = msm_digit_kernel<CC, SCATTER>;                      \
+#define ZK_CASE_T(CC, BIG)                                         \
+  {                                                                \
+    auto kfn = msm_digit_kernel<CC, SCATTER, BIG>;                 \
     if (shmem > 65536) ZK_HIP(ctx, hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)); \
-    ZK_LAUNCH(ctx, nm, kfn, grid, block, shmem, a);                \
-  } break;
-    ZK_CASE(8) ZK_CASE(9) ZK_CASE(10) ZK_CASE(11) ZK_CASE(12) ZK_CASE(13) ZK_CASE(14) ZK_CASE(15) ZK_CASE(16)
+    ZK_LAUNCH(ctx, nm, kfn, grid, dim3(BIG ? 1024 : MSM_THREADS), shmem, a); \
+  }
+#define ZK_CASE(CC) \
+  case CC:          \
+    ZK_CASE_T(CC, false) break;
+#define ZK_CASE2(CC)               \
+  case CC:                         \
+    if (big) ZK_CASE_T(CC, true)   \
+    else ZK_CASE_T(CC, false)      \
+    break;
+    ZK_CASE(8) ZK_CASE(9) ZK_CASE(10) ZK_CASE(11) ZK_CASE(12) ZK_CASE(13) ZK_CASE2(14) ZK_CASE2(15) ZK_CASE2(16)
 #undef ZK_CASE
+#undef ZK_CASE2
+#undef ZK_CASE_T
     default:
       ZK_FAIL(ctx, AMDZK_E_INVALID, "msm: window bits %u unsupported", c);
   }
@@ -980,6 +1028,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // own end, so that group g's tail and group g + 2's sort run UNDER group g + 1's level-1 kernel (zk_msm_dev_xyzz).
 struct MsmGeom {
   uint32_t c, W, nb, T1, TL, chunk, nblk;
+  bool big_digits;  // counting sort with 1024-thread workgroups, up to 256 of them per column
   size_t ecap, cap[4], G;
   size_t o_bh, o_cnt, o_off[4], o_ent, o_list[4], o_dense, o_rows, o_cols, bytes;
 };
@@ -1001,15 +1050,22 @@ static MsmGeom msm_geometry(const amdzk_srs* srs, size_t ncols, size_t len, size
   g.T1 = 4;
   if (e_total > (size_t)4 * 262144) g.T1 = 8;
   if (e_total > (size_t)8 * 262144) g.T1 = 12;
+  // one long column (k >= 19): tens of millions of entries keep the chip full whatever the task size, and every partial
+  // sum a task leaves behind is one more addition in the folds (profiles/r04a_*: 2^22 points, T1 = 12 / 24 / 32 / 48)
+  if (g.ecap >= ((size_t)1 << 23)) g.T1 = 32;
   if (const char* e = getenv("AMDZK_MSM_T1")) g.T1 = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : g.T1;
   g.TL = 6;  // 4 / 6 / 8 / 12 / 16 prove at the same rate (76.7-78.0 proofs/s); 6 has the shortest proof (profiles/r02j_msm_task_size.txt)
   if (const char* e = getenv("AMDZK_MSM_TL")) g.TL = (uint32_t)atoi(e) > 1 ? (uint32_t)atoi(e) : g.TL;
   g.cap[0] = g.ecap;
   g.cap[1] = g.ecap / g.T1 + g.nb + 1;
   for (int l = 2; l <= MSM_NLEV; l++) g.cap[l] = g.cap[l - 1] / g.TL + g.nb + 1;
-  // counting-sort geometry: one workgroup per `chunk` scalars, at most 64 workgroups per column
-  g.chunk = 2048;
-  while ((len + g.chunk - 1) / g.chunk > 64) g.chunk <<= 1;
+  // counting-sort geometry: one workgroup per `chunk` scalars, at most 64 workgroups per column — 256 workgroups of 1024
+  // threads when the batch is a few long columns (msm_digit_kernel<.., BIG>: window widths 14-16 only)
+  g.big_digits = g.c >= 14 && len >= ((size_t)1 << 18) && ncols * ((len + 65535) / 65536) < 256;
+  if (const char* e = getenv("AMDZK_MSM_BIG_DIGITS")) g.big_digits = g.c >= 14 && atoi(e) != 0;
+  const size_t maxblk = g.big_digits ? 256 : 64;
+  g.chunk = g.big_digits ? 4096 : 2048;
+  while ((len + g.chunk - 1) / g.chunk > maxblk) g.chunk <<= 1;
   g.nblk = len ? (uint32_t)((len + g.chunk - 1) / g.chunk) : 1;
   size_t o = 0;
   auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
@@ -1022,7 +1078,7 @@ static MsmGeom msm_geometry(const amdzk_srs* srs, size_t ncols, size_t len, size
   g.o_dense = take(ncols * g.nb * sizeof(G1X29));
   g.G = g.nb >> 6;
   g.o_rows = take(ncols * g.G * sizeof(G1X29));
-  g.o_cols = take(ncols * 64 * sizeof(G1X29));
+  g.o_cols = take(ncols * ((g.G + 63) / 64) * 64 * sizeof(G1X29));
   g.bytes = o;
   return g;
 }
@@ -1052,10 +1108,10 @@ static int msm_group(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const MsmG
   da.ecap = g.ecap;
   da.table_n = (uint32_t)srs->n;
   dim3 dgrid(g.nblk, (unsigned)ncols);
-  ZK_TRY(launch_digits<false>(ctx, g.c, da, dgrid));
+  ZK_TRY(launch_digits<false>(ctx, g.c, da, dgrid, g.big_digits));
   ZK_LAUNCH(ctx, "msm_blk_offsets", msm_blk_offsets_kernel, dim3((nb + 255) / 256, (unsigned)ncols), dim3(256), 0, blk_hist, cnt, nb, g.nblk);
   ZK_LAUNCH(ctx, "msm_scan", msm_scan_kernel, dim3((unsigned)ncols), dim3(1024), 0, cnt, off[0], nb, 1u, 1);
-  ZK_TRY(launch_digits<true>(ctx, g.c, da, dgrid));
+  ZK_TRY(launch_digits<true>(ctx, g.c, da, dgrid, g.big_digits));
   for (int l = 1; l <= MSM_NLEV; l++) {
     const uint32_t T = l == 1 ? g.T1 : g.TL;
     ZK_LAUNCH(ctx, "msm_scan", msm_scan_kernel, dim3((unsigned)ncols), dim3(1024), 0, off[l - 1], off[l], nb, T, 2);
@@ -1083,7 +1139,7 @@ static int msm_group(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const MsmG
   }
   ZK_LAUNCH(ctx, "msm_accum_final", msm_accum_final_kernel, dim3(nb / 64, (unsigned)ncols), dim3(64), 0, off[MSM_NLEV], nb, list[MSM_NLEV],
             g.cap[MSM_NLEV], dense);
-  ZK_LAUNCH(ctx, "msm_rowcol", msm_rowcol_kernel, dim3((unsigned)(1 + (g.G + 63) / 64), (unsigned)ncols), dim3(64 * ROWCOL_WAVES), 0, dense, nb, rows,
+  ZK_LAUNCH(ctx, "msm_rowcol", msm_rowcol_kernel, dim3((unsigned)(2 * ((g.G + 63) / 64)), (unsigned)ncols), dim3(64 * ROWCOL_WAVES), 0, dense, nb, rows,
             cols);
   const unsigned fold_w = (unsigned)((g.G + 63) / 64);  // 1, 2, 4 or 8 (c <= 16): at most 9 wavefronts per workgroup (launch bound 576)
   ZK_LAUNCH(ctx, "msm_fold", msm_fold_kernel, dim3((unsigned)ncols), dim3(64 * (fold_w + 1)), 0, rows, cols, nb, outp);
@@ -1119,6 +1175,7 @@ int zk_msm_dev_xyzz(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const Fr* d
   if (!ctx->msm_l1_evt) ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->msm_l1_evt, hipEventDisableTiming));
   if (ngroups == 1) {
     ZK_TRY(msm_group(ctx, srs, basis, g, ws, d_scalars, ncols, len, col_stride, outp, nullptr, ctx->msm_l1_evt));
+    ctx->msm_l1_fresh = true;
     *d_out = outp;
     return AMDZK_OK;
   }
@@ -1138,6 +1195,7 @@ int zk_msm_dev_xyzz(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const Fr* d
   }
   ctx->stream = main_stream;
   ZK_TRY(rc);
+  ctx->msm_l1_fresh = true;
   ZK_HIP(ctx, hipEventRecord(ctx->msm_evt[7], ctx->msm_stream));
   ZK_HIP(ctx, hipStreamWaitEvent(main_stream, ctx->msm_evt[7], 0));
   *d_out = outp;

@@ -37,6 +37,7 @@ class WitnessStream:
         self.bufs = [ctx.alloc(nbytes), ctx.alloc(nbytes)]
         self.cur = 0
         self.pending = False
+        self.pending_src = None
 
     def prefetch(self, pinned):
         """Start copying `pinned` (PinnedWitness) into the idle buffer. The previous reader of that buffer — the
@@ -45,6 +46,7 @@ class WitnessStream:
         assert pinned.nbytes <= self.nbytes
         self.ctx.upload_async(self.bufs[self.cur ^ 1], pinned.ptr, pinned.nbytes)
         self.pending = True
+        self.pending_src = pinned
 
     def acquire(self):
         """The buffer holding the most recently prefetched witness; everything submitted to the ctx from now on
@@ -53,6 +55,7 @@ class WitnessStream:
         self.ctx.upload_fence()
         self.cur ^= 1
         self.pending = False
+        self.pending_src = None
         return self.bufs[self.cur]
 
     def free(self):
@@ -60,16 +63,25 @@ class WitnessStream:
             b.free()
 
 
-def prove_stream(plonk, ctx, pk, stream, items, transcript=0):
+def prove_stream(plonk, ctx, pk, stream, items, transcript=0, then=None):
     """create_proof for each (pinned_witness, instances, seed) of `items` on one context, with the next witness's
-    upload overlapped with the current proof. Returns the proofs in order."""
+    upload overlapped with the current proof. Returns the proofs in order.
+
+    `then`: the pinned witness the NEXT call on this stream starts with. Its upload is issued before this call's last
+    proof, so a caller that proves in rounds (bench.py's timed regions, a service's batches) keeps the pipeline full
+    across rounds: every call issues exactly len(items) uploads, none of them exposed. A stream that a previous call
+    primed this way must be continued with that same witness."""
     out = []
     if not items:
         return out
-    stream.prefetch(items[0][0])
+    if stream.pending:
+        assert stream.pending_src is items[0][0], "the stream was primed with another witness than this call starts with"
+    else:
+        stream.prefetch(items[0][0])
     for j, (_, inst, seed) in enumerate(items):
         buf = stream.acquire()
-        if j + 1 < len(items):
-            stream.prefetch(items[j + 1][0])
+        nxt = items[j + 1][0] if j + 1 < len(items) else then
+        if nxt is not None:
+            stream.prefetch(nxt)
         out.append(plonk.create_proof(ctx, pk, inst, buf, seed=seed, transcript=transcript))
     return out

@@ -30,6 +30,7 @@ def lib():
     vp, sz, u32, i32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int
     sig = {
         "amdzk_version": (i32, []),
+        "amdzk_build_info": (C.c_char_p, []),
         "amdzk_init": (i32, [i32, C.POINTER(vp)]),
         "amdzk_destroy": (None, [vp]),
         "amdzk_last_error": (C.c_char_p, [vp]),
@@ -109,6 +110,15 @@ def lib():
     L._amdzk_sig = sig
     _LIB = L
     return L
+
+
+def build_info():
+    """amdzk_build_info(): "amdzk <abi> src=<hash> arch=gfx950" -> {"abi": .., "src": .., "arch": ..}."""
+    txt = lib().amdzk_build_info().decode()
+    parts = txt.split()
+    out = {"text": txt, "abi": int(parts[1])}
+    out.update(dict(kv.split("=", 1) for kv in parts[2:]))
+    return out
 
 
 def _ptr(a):
@@ -200,7 +210,8 @@ class Context:
         self._chk(self.L.amdzk_sync(self.h))
 
     def set_host_wait(self, block):
-        """amdzk_set_host_wait: block=True, waits sleep on a blocking-sync event; False, they spin (the default)."""
+        """amdzk_set_host_wait: block=True, host waits POLL a completion event (20 us of yielding, then 50-us sleeps: each
+        wait ends up to ~50 us late, 8-10 waits per proof); False, they spin in hipStreamSynchronize (the default)."""
         self._chk(self.L.amdzk_set_host_wait(self.h, 1 if block else 0))
 
     def device(self):

@@ -162,6 +162,7 @@ class GpuProver:
 
         self.np, self.torch = np, torch
         pkg = self.pkg = ge.load_package()
+        check_library_stamp(pkg)
         self.plonk = pkg.plonk
         wl = pkg.workloads
         self.P = P
@@ -253,10 +254,12 @@ class GpuProver:
             self.pinned.append(pw)
         self.streams = [fd.WitnessStream(cx, A * self.n * 32) for cx in self.ctxs]
 
-    def prove_stream(self, w, jobs):
-        """jobs: [(witness index, seed)] for worker w, proved with one upload per proof."""
+    def prove_stream(self, w, jobs, then=None):
+        """jobs: [(witness index, seed)] for worker w, proved with one upload per proof; `then` = the witness index the
+        next call on this worker starts with (its upload is issued before this call's last proof: feeder.prove_stream)."""
         items = [(self.pinned[wi], self.inst[wi], seed) for wi, seed in jobs]
-        return self.pkg.feeder.prove_stream(self.plonk, self.ctxs[w], self.pks[w], self.streams[w], items)
+        return self.pkg.feeder.prove_stream(self.plonk, self.ctxs[w], self.pks[w], self.streams[w], items,
+                                            then=None if then is None else self.pinned[then])
 
     def close(self):
         if self.streams:
@@ -270,6 +273,16 @@ class GpuProver:
         self.params.free()
         for cx in self.ctxs:
             cx.close()
+
+
+def check_library_stamp(pkg):
+    """libamdzk.so must have been built from THIS tree's kernel sources (amdzk_build_info() carries their hash): a stale
+    binary that travelled with the snapshot would otherwise be measured under the new sources' name."""
+    have, want = pkg.build_info().get("src"), kernel_src_hash()
+    if have != want and os.environ.get("AMDZK_BENCH_ALLOW_STALE_LIB") != "1":
+        raise SystemExit("bench.py: libamdzk.so was built from kernel sources %s, this tree's are %s: rebuild "
+                         "(python -c 'import __graft_entry__ as g; g.build()')" % (have, want))
+    return have
 
 
 class StubProver:
@@ -297,7 +310,7 @@ class StubProver:
     def stream_setup(self):
         self.streams = True
 
-    def prove_stream(self, w, jobs):
+    def prove_stream(self, w, jobs, then=None):
         return [self.prove(w, wi, seed) for wi, seed in jobs]
 
     def close(self):
@@ -441,20 +454,60 @@ def run_rank(args):
             cx.set_host_wait(block_waits)
     run_pool(P, list(range(P)), warm_context)
     prover.check_affinity()
-    # the timed region, R times over: same steps, fresh blinding seeds; region 0's proofs are the ones gathered and
-    # compared with the streamed pass. Reported: the median region.
-    regions, proofs = [], None
-    for reg in range(max(1, args.regions)):
-        jobs_r = [(wi, seed + 100000 * reg) for wi, seed in jobs]
-        barrier()
-        c0 = time.process_time()
-        t0 = time.perf_counter()
-        pr = run_pool(P, jobs_r, lambda w, j: prover.prove(w, j[0], j[1]))
-        barrier()
-        regions.append((max_over_ranks(time.perf_counter() - t0), time.process_time() - c0))
-        if reg == 0:
-            proofs = pr
+    # The timed region, R times over: same steps, fresh blinding seeds; the median region is reported. Worker w (one
+    # context, one host thread) proves steps w, w + P, w + 2P, ... of a region.
+    #   streamed (the default, and `value`): every proof's witness crosses PCIe once — pinned host memory -> one of the
+    #     context's two device buffers on its copy stream — while the context's previous proof runs; the upload for a
+    #     region's first proof is issued before the previous region's last proof (a service's steady state), so each region
+    #     issues exactly `steps` uploads and the first P witnesses are in HBM when a region starts.
+    #   resident (`config.resident_proofs_per_s`, the figure rounds 1-3 called `value`): the witnesses stay in HBM.
+    # Region 0 of both passes uses the same seeds: the proofs must be the same bytes.
+    per_worker = [[j for i, j in enumerate(jobs) if i % P == w] for w in range(P)]
+    R_ = max(1, args.regions)
+
+    def region_items(reg):
+        return [[(wi, seed + 100000 * reg) for wi, seed in per_worker[w]] for w in range(P)]
+
+    def run_regions(streamed):
+        regs, first = [], None
+        if streamed:
+            # untimed: both halves of every double buffer touched once, and the pipeline primed with region 0's first witness
+            run_pool(P, list(range(P)), lambda _, cx: prover.prove_stream(
+                cx, [(wi, seed + 900000) for wi, seed in per_worker[cx][:2]], then=per_worker[cx][0][0] if per_worker[cx] else None))
+        for reg in range(R_):
+            items = region_items(reg)
+            barrier()
+            c0 = time.process_time()
+            t0 = time.perf_counter()
+            if streamed:
+                nxt = reg + 1 < R_
+                pr = run_pool(P, list(range(P)), lambda _, cx: prover.prove_stream(
+                    cx, items[cx], then=per_worker[cx][0][0] if (nxt and per_worker[cx]) else None))
+            else:
+                pr = run_pool(P, list(range(P)), lambda _, cx: [prover.prove(cx, wi, seed) for wi, seed in items[cx]])
+            barrier()
+            regs.append((max_over_ranks(time.perf_counter() - t0), time.process_time() - c0))
+            if reg == 0:
+                first = [None] * steps
+                for w in range(P):
+                    for q, proof in enumerate(pr[w]):
+                        first[w + q * P] = proof
+        return regs, first
+
+    stream_equal = None
+    streamed_value = not args.no_stream_pass
+    if streamed_value:
+        prover.stream_setup()
+        regions, proofs = run_regions(True)
+        res_regions, res_proofs = run_regions(False)
+        stream_equal = res_proofs == proofs
+        if not stream_equal:
+            raise SystemExit("bench.py: proofs from streamed witnesses differ from the resident-witness proofs")
+    else:
+        regions, proofs = run_regions(False)
+        res_regions = regions
     dt, host_cpu_s = sorted(regions)[len(regions) // 2]
+    res_dt = sorted(res_regions)[len(res_regions) // 2][0]
     gathered_ok = None
     if dist_on:
         # the one exchange step: every rank's proofs (equal length) gathered on all ranks (RCCL all_gather)
@@ -468,26 +521,6 @@ def run_rank(args):
             all(gathered[s * world + rank] == proofs[s] for s in range(steps))
         if not gathered_ok:
             raise SystemExit("bench.py: gathered proofs do not match this rank's proofs")
-
-    # PCIe-inclusive pass: the same steps, one witness upload per proof (double-buffered per context)
-    stream_rate = stream_equal = None
-    if not args.no_stream_pass:
-        prover.stream_setup()
-        per_worker = [[j for i, j in enumerate(jobs) if i % P == w] for w in range(P)]
-        run_pool(P, list(range(P)), lambda _, cx: prover.prove_stream(cx, per_worker[cx][:1]))  # untimed: buffers touched once
-        barrier()
-        t1 = time.perf_counter()
-        sp = run_pool(P, list(range(P)), lambda _, cx: prover.prove_stream(cx, per_worker[cx]))
-        barrier()
-        dts = max_over_ranks(time.perf_counter() - t1)
-        stream_rate = world * steps / dts
-        flat = {}
-        for w in range(P):
-            for (wi, seed), p in zip(per_worker[w], sp[w]):
-                flat[(wi, seed)] = p
-        stream_equal = all(flat[j] == p for j, p in zip(jobs, proofs))
-        if not stream_equal:
-            raise SystemExit("bench.py: proofs from streamed witnesses differ from the resident-witness proofs")
 
     # host cores of every rank (count, first id, last id) for the line
     my_mask = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
@@ -530,7 +563,7 @@ def run_rank(args):
                 "dtype": "u32 limbs (254-bit Montgomery integers: 9 x 29-bit in the hot products, 8 x 32-bit elsewhere)",
                 "data": "stub" if stub else "synthetic",
                 "config": {"workload": "create_proof, %s: %d advice, %d lookups, %d permutation columns, degree %d, "
-                                       "KZG/SHPLONK/Blake2b, %d distinct witnesses per GPU resident in HBM"
+                                       "KZG/SHPLONK/Blake2b, %d distinct witnesses per GPU cycled through"
                                        % (args.shape, desc["num_advice"], len(desc["lookups"]), len(desc["permutation_columns"]),
                                           desc["cs_degree"], nw),
                            "k": prover.K, "extended_k": prover.K + max(0, (desc["cs_degree"] - 2).bit_length()),
@@ -538,6 +571,14 @@ def run_rank(args):
                            "batch": args.batch or None, "proofs_total": world * steps,
                            "warmup_proofs_untimed": max(args.warmup, 0) * P,
                            "value_samples": [round(world * steps / r[0], 4) for r in regions],
+                           "value_is": ("streamed: one %.0f MiB witness upload per proof (pinned host memory -> device on the context's copy "
+                                        "stream, double-buffered, the next proof's upload under the current proof; the first %d witnesses "
+                                        "are in HBM when a region starts)" % (desc["num_advice"] * prover.n * 32 / 2 ** 20, P)) if streamed_value
+                           else "resident witnesses (--no-stream-pass)",
+                           "resident_proofs_per_s": round(world * steps / res_dt, 4),
+                           "resident_samples": [round(world * steps / r[0], 4) for r in res_regions],
+                           "streamed_over_resident": round(res_dt / dt, 4),
+                           "streamed_equals_resident_bytes": stream_equal,
                            "timed_regions": len(regions),
                            "host_cpu_s_per_proof": round(host_cpu_s / steps, 5), "host_threads": min(P, steps) + 1,
                            "host_cores_allowed": cores_allowed,
@@ -552,15 +593,13 @@ def run_rank(args):
                            "latency_note": "one proof in flight, median of 3; default key = the proof's independent work on three "
                                            "streams (lanes), serial key (AMDZK_KEYGEN_SERIAL) = one stream; same proof bytes",
                            "k22_stress": k22,
-                           "pcie_inclusive_proofs_per_s": round(stream_rate, 4) if stream_rate else None,
-                           "pcie_inclusive_note": "same steps with one %.0f MiB witness upload per proof from pinned host memory on a copy "
-                                                  "stream, double-buffered per in-flight context; proofs byte-equal to the resident run"
-                                                  % (desc["num_advice"] * prover.n * 32 / 2 ** 20) if stream_rate else None,
+                           "pcie_inclusive_proofs_per_s": round(world * steps / dt, 4) if streamed_value else None,
                            "gather": ("all_gather of %d proofs, every rank's own proofs found in place" % (world * steps)) if gathered_ok else None,
                            "parallelism": "independent proofs sharded across GPUs, %d in flight per GPU" % P,
                            "key_mode": ("serial keys for the timed steps (one stream per proof; %d proofs in flight fill the chip), "
                                         "default lanes key for single_proof_latency_ms" % P) if getattr(prover, "serial_keys", False)
                            else "default (lanes) keys",
+                           "library_build": None if stub else prover.pkg.build_info()["text"],
                            "setup_s_excluded": round(prover.setup_s, 1)},
                 "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(line), flush=True)

@@ -59,6 +59,9 @@ void amdzk_destroy(amdzk_ctx* ctx);
 const char* amdzk_last_error(const amdzk_ctx* ctx);
 /* ABI version of this header: major*1000 + minor. */
 int amdzk_version(void);
+/* "amdzk <abi> src=<16 hex digits> arch=gfx950": the hash is over the comment-stripped kernel sources and build flags the
+ * binary was made from (csrc/Makefile stamps it; the same function as bench.kernel_src_hash()). A static string. */
+const char* amdzk_build_info(void);
 /* Run subsequent work of this ctx on an existing hipStream_t (e.g. torch's current stream);
  * NULL restores the ctx's own stream. */
 int amdzk_set_stream(amdzk_ctx* ctx, void* hip_stream);
@@ -71,9 +74,15 @@ int amdzk_ctx_device(const amdzk_ctx* ctx);
 int amdzk_ctx_check_affinity(amdzk_ctx* ctx);
 int amdzk_ptr_check_affinity(amdzk_ctx* ctx, const void* dptr);
 /* How this context's calls wait for the device: AMDZK_WAIT_SPIN (default; hipStreamSynchronize — lowest latency, the
- * waiting thread keeps a core busy) or AMDZK_WAIT_BLOCK (the thread sleeps on a blocking-sync event: for hosts that keep
- * more proofs in flight than they have cores to spare — one GPU's share of an 8-GPU host is 2 cores on the reference box,
- * where spinning costs 17 % of the rate). Default from AMDZK_HOST_WAIT=spin|block when the ctx is made. */
+ * waiting thread keeps a core busy) or AMDZK_WAIT_BLOCK: the thread POLLS a completion event — hipEventQuery, 20 us of
+ * yielding, then 50-us sleeps — and leaves its core to the threads that have kernels to launch. Every polled wait ends up
+ * to one sleep quantum (about 50 us) late and a proof has 8-10 of them, so a lone proof is about 0.3-0.5 ms slower; it is
+ * for hosts that keep more proofs in flight than they have cores to spare — one GPU's share of an 8-GPU host is 2 cores on
+ * the reference box, where spinning costs 17 % of the rate, DESIGN.md §5. (The runtime's own blocking waits are not used:
+ * hipEventBlockingSync events still spin on this ROCm.) Default from AMDZK_HOST_WAIT=spin|block when the ctx is made.
+ * A host process that runs the device with hipDeviceScheduleBlockingSync (hipSetDeviceFlags) gets polling waits on EVERY
+ * host wait of this library whatever this setting says: amdzk_init reads hipGetDeviceFlags and the library then never
+ * enters the runtime's blocking waits (first screen). */
 #define AMDZK_WAIT_SPIN 0
 #define AMDZK_WAIT_BLOCK 1
 int amdzk_set_host_wait(amdzk_ctx* ctx, int mode);

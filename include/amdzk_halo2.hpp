@@ -54,8 +54,9 @@ class Context {
   void check(int rc) const {
     if (rc != AMDZK_OK) throw Error(rc, amdzk_last_error(h_));
   }
-  // amdzk_set_host_wait: true = this context's calls sleep while they wait for the device (hosts with more proofs in
-  // flight than cores to spare), false = they spin (the default: lowest latency)
+  // amdzk_set_host_wait: true = this context's calls POLL a completion event while they wait for the device (20 us of
+  // yielding, then 50-us sleeps: every wait ends up to ~50 us late, 8-10 waits per proof; for hosts with more proofs in
+  // flight than cores to spare), false = they spin in hipStreamSynchronize (the default: lowest latency)
   void set_blocking_waits(bool block) const { check(amdzk_set_host_wait(h_, block ? AMDZK_WAIT_BLOCK : AMDZK_WAIT_SPIN)); }
 
  private:
