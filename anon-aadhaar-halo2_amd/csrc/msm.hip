@@ -218,11 +218,24 @@ __global__ __launch_bounds__(256) void msm_blk_offsets_kernel(uint32_t* blk_hist
 //   mode 1: v[b] = src[b]                       (src has nb entries per column)
 //   mode 0: v[b] = ceil((src[b+1]-src[b]) / T)   (src has nb+1 entries per column)
 //   mode 2: v[b] = number of T-aligned chunks of the whole list that intersect [src[b], src[b+1])
+// The source row is first copied into LDS with coalesced loads (thread t takes words t, t + 1024, ...: all of a thread's
+// loads in flight at once) — a thread walking its own `per` consecutive words straight from global memory waits for one
+// dependent load after the other: 62 us per launch at 2^15 buckets, 15 us staged (profiles/r04a_*). Rows of up to
+// SCAN_LDS_WORDS words (buckets + 1) are staged; longer ones are read in place.
+constexpr uint32_t SCAN_LDS_WORDS = 32768 + 1;
 __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* src, uint32_t* off_out,
                                                          uint32_t nb, uint32_t T, int src_is_hist) {
-  __shared__ uint32_t wtot[16];
+  extern __shared__ uint32_t scan_lds[];  // [16] wavefront totals, then the staged row
+  uint32_t* wtot = scan_lds;
   const uint32_t col = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const uint32_t* s = src + (size_t)col * (src_is_hist == 1 ? nb : nb + 1);
+  const uint32_t words = src_is_hist == 1 ? nb : nb + 1;
+  const uint32_t* s = src + (size_t)col * words;
+  if (words <= SCAN_LDS_WORDS) {
+    uint32_t* st = scan_lds + 16;
+    for (uint32_t i = t; i < words; i += 1024) st[i] = s[i];
+    __syncthreads();
+    s = st;
+  }
   uint32_t* o = off_out + (size_t)col * (nb + 1);
   const uint32_t per = (nb + 1023) / 1024;
   const uint32_t b0 = t * per, b1 = min(b0 + per, nb);
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* src, uin
   }
   __syncthreads();
   uint32_t run = inc - sum + (wv ? wtot[wv - 1] : 0u);
-  for (uint32_t b = b0; b < b1; b++) {
+  for (uint32_t b = b0; b < b1; b++) {  // stores do not wait for each other
     o[b] = run;
     run += val(b);
   }
@@ -361,6 +374,150 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_accum_seg_kernel(AccArgs a) {
     }
   }
   st_x29(out + off_out[b] + (t - off_in[b] / a.T), acc);
+}
+
+// Level 1 as a PERSISTENT grid (AMDZK_L1_LDS=9; round-4 experiment, profiles/r04b_*): a fixed number of workgroups, each
+// fetching (column, block) items from an atomic counter — items are numbered block-major, so the blocks that hold entries
+// come first whatever the column — instead of one workgroup per 256 * T entries of CAPACITY: the grid of the generic
+// kernel is sized on len * W entries per column, and a witness column (5-6 non-zero digits per scalar of 20) leaves 70 %
+// of its workgroups with nothing to do. Same arithmetic, same slots, same results.
+__global__ __launch_bounds__(MSM_THREADS) void msm_accum_l1_persist_kernel(AccArgs a, uint32_t* counter, uint32_t blocks_x, uint32_t ncols) {
+  __shared__ uint32_t s_item;
+  for (;;) {
+    if (threadIdx.x == 0) s_item = atomicAdd(counter, 1u);
+    __syncthreads();
+    const uint32_t item = s_item;
+    __syncthreads();
+    if (item >= blocks_x * ncols) return;
+    const uint32_t col = item % ncols, bx = item / ncols;
+    const uint32_t t = bx * blockDim.x + threadIdx.x;
+    const uint32_t* off_in = a.off_in + (size_t)col * (a.nb + 1);
+    const uint32_t* off_out = a.off_out + (size_t)col * (a.nb + 1);
+    const uint32_t total = off_in[a.nb];
+    const uint32_t start = t * a.T;
+    if (start >= total) continue;
+    const uint32_t end = min(start + a.T, total);
+    uint32_t lo = 0, hi = a.nb;
+    while (hi - lo > 1) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (off_in[mid] <= start) lo = mid; else hi = mid;
+    }
+    uint32_t b = lo, b_end = off_in[b + 1];
+    const uint32_t* ent = a.entries + (size_t)col * a.ecap;
+    G1X29* out = a.out_list + (size_t)col * a.out_cap;
+    G1X29 acc = G1X29::inf();
+    for (uint32_t e = start; e < end; e++) {
+      if (e >= b_end) {
+        st_x29(out + off_out[b] + (t - off_in[b] / a.T), acc);
+        acc = G1X29::inf();
+        do {
+          b++;
+          b_end = off_in[b + 1];
+        } while (e >= b_end);
+      }
+      const uint32_t id = ent[e];
+      G1Affine p = ld_aff(a.table + (id & 0x7fffffffu));
+      const bool p_inf = p.is_inf();
+      if (id >> 31) p.y = neg(p.y);
+      acc = x29_add_affine(acc, fq29_unpack(p.x), fq29_unpack(p.y), p_inf);
+    }
+    st_x29(out + off_out[b] + (t - off_in[b] / a.T), acc);
+  }
+}
+
+// Level 1 with the XYZZ accumulator in LDS (AMDZK_L1_LDS=1; round-4 experiment, profiles/r04b_*): the generic kernel above
+// keeps 36 accumulator limbs + 18 limbs of the table point + the temporaries of the addition in registers — 152 VGPRs,
+// three wavefronts per SIMD. Here the accumulator lives in LDS as [word][thread] (conflict-free 32-bit accesses, 36 KiB
+// per 256-thread workgroup, four workgroups per compute unit) and each coordinate is read where the formula needs it
+// and written back when its new value exists: 12 coordinate moves (108 LDS words) per 2,160-instruction addition.
+constexpr int L1L_THREADS = 256;
+struct LdsAcc {
+  uint32_t* base;  // &lds[threadIdx.x]; word w of this thread's accumulator at base[w * L1L_THREADS]
+  __device__ __forceinline__ Fq29 ld(int f) const {
+    Fq29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = base[(f * 9 + i) * L1L_THREADS];
+    return r;
+  }
+  __device__ __forceinline__ void st(int f, const Fq29& v) const {
+#pragma unroll
+    for (int i = 0; i < 9; i++) base[(f * 9 + i) * L1L_THREADS] = v.l[i];
+  }
+  __device__ __forceinline__ G1X29 all() const {
+    G1X29 r;
+    r.x = ld(0); r.y = ld(1); r.zz = ld(2); r.zzz = ld(3);
+    return r;
+  }
+};
+template <int WAVES>
+__global__ __launch_bounds__(L1L_THREADS, WAVES) void msm_accum_l1_lds_kernel(AccArgs a) {
+  __shared__ uint32_t lds[36 * L1L_THREADS];
+  const uint32_t col = blockIdx.y;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t* off_in = a.off_in + (size_t)col * (a.nb + 1);
+  const uint32_t* off_out = a.off_out + (size_t)col * (a.nb + 1);
+  const uint32_t total = off_in[a.nb];
+  const uint32_t start = t * a.T;
+  if (start >= total) return;
+  const uint32_t end = min(start + a.T, total);
+  uint32_t lo = 0, hi = a.nb;
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (off_in[mid] <= start) lo = mid; else hi = mid;
+  }
+  uint32_t b = lo, b_end = off_in[b + 1];
+  const uint32_t* ent = a.entries + (size_t)col * a.ecap;
+  G1X29* out = a.out_list + (size_t)col * a.out_cap;
+  const LdsAcc A{lds + threadIdx.x};
+  bool acc_inf = true;
+  for (uint32_t e = start; e < end; e++) {
+    if (e >= b_end) {
+      st_x29(out + off_out[b] + (t - off_in[b] / a.T), acc_inf ? G1X29::inf() : A.all());
+      acc_inf = true;
+      do {
+        b++;
+        b_end = off_in[b + 1];
+      } while (e >= b_end);
+    }
+    const uint32_t id = ent[e];
+    G1Affine p = ld_aff(a.table + (id & 0x7fffffffu));
+    if (p.is_inf()) continue;
+    if (id >> 31) p.y = neg(p.y);
+    const Fq29 qx = fq29_unpack(p.x), qy = fq29_unpack(p.y);
+    if (acc_inf) {
+      A.st(0, qx);
+      A.st(1, qy);
+      A.st(2, f29_one<Fq29P>());
+      A.st(3, f29_one<Fq29P>());
+      acc_inf = false;
+      continue;
+    }
+    const Fq29 u2 = f29_mul(qx, A.ld(2));
+    const Fq29 s2 = f29_mul(qy, A.ld(3));
+    const Fq29 pd = f29_sub10(u2, A.ld(0));
+    const Fq29 r = f29_sub6(s2, A.ld(1));
+    const Fq29 pp = f29_sqr(pd);
+    const Fq29 rr = f29_sqr(r);
+    if (f29_is_zero_mod_p(pp)) {
+      if (f29_is_zero_mod_p(rr)) {
+        const G1X29 d = x29_dbl_affine(qx, qy);
+        A.st(0, d.x); A.st(1, d.y); A.st(2, d.zz); A.st(3, d.zzz);
+      } else {
+        acc_inf = true;
+      }
+      continue;
+    }
+    const Fq29 ppp = f29_mul(pd, pp);
+    const Fq29 q = f29_mul(A.ld(0), pp);
+    const Fq29 s = f29_add(ppp, f29_add_lazy(q, q));
+    const Fq29 ox = f29_sub7(rr, s);
+    A.st(0, ox);
+    const Fq29 tq = f29_sub10_lazy(q, ox);
+    A.st(1, f29_mul2(r, tq, f29_neg6(A.ld(1)), ppp));
+    A.st(2, f29_mul(A.ld(2), pp));
+    A.st(3, f29_mul(A.ld(3), ppp));
+  }
+  st_x29(out + off_out[b] + (t - off_in[b] / a.T), acc_inf ? G1X29::inf() : A.all());
 }
 
 // ------------------------------------------------------------------ wavefront reductions
@@ -521,7 +678,10 @@ __device__ __forceinline__ G1X x_mul_small(const G1X& p, uint32_t k, int nbits) 
 // Horner (6 doublings per factor 64). The kernel is pure latency, one workgroup per column, at the end of every
 // commitment batch. The result leaves in the packed radix-2^256 XYZZ form (x29_to_r256): the only radix conversion of
 // the whole MSM.
-__global__ __launch_bounds__(576) void msm_fold_kernel(const G1X29* rows, const G1X29* cols, uint32_t nb, G1X* out) {
+// MAXW: the most row-sum wavefronts a workgroup may have (1 up to 2^12 buckets, i.e. every proof-sized MSM: two wavefronts,
+// the whole register file each; 8 for the window widths of k >= 19).
+template <int MAXW>
+__global__ __launch_bounds__(64 * (MAXW + 1)) void msm_fold_kernel(const G1X29* rows, const G1X29* cols, uint32_t nb, G1X* out) {
   __shared__ G1X29 partA[8], partB[8], partC;
   const uint32_t col = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const uint32_t G = nb >> 6, W = (G + 63) >> 6;
@@ -544,24 +704,27 @@ __global__ __launch_bounds__(576) void msm_fold_kernel(const G1X29* rows, const 
   }
   __syncthreads();
   if (wv == 0) {
-    G1X29 sum_b = partB[0], acc = partA[0];
+    G1X29 acc;
     if (W > 1) {
-      // wavefront 0, lanes w < W (<= 8): acc = sum_w A_w, sum_b = sum_w B_w, and Y = sum_w w B_w = the sum of the suffix
-      // sums of B over w = 1 .. W - 1 — three shuffle rounds each instead of lane 0 walking the W values three times
-      const G1X29 a = lane < W ? partA[lane] : G1X29::inf();
-      const G1X29 b = lane < W ? partB[lane] : G1X29::inf();
-      const G1X29 sufb = wave_suffix29_n(b, lane, 8);
-      acc = wave_sum29_n(a, 8);
-      G1X29 y = wave_sum29_n(lane == 0 || lane >= W ? G1X29::inf() : sufb, 8);
-      sum_b = sufb;  // lane 0: the plain sum
+      // wavefront 0, lanes w < W (<= 8): Y = sum_w w B_w = the sum of the suffix sums of B over w = 1 .. W - 1, sum_w B_w (the
+      // suffix sum of lane 0, parked in partB[0]) and sum_w A_w — three shuffle rounds each instead of lane 0 walking the
+      // W values three times. One point live at a time beside the running one: the kernel may hold 168 registers.
+      G1X29 y;
+      {
+        const G1X29 sufb = wave_suffix29_n(lane < W ? partB[lane] : G1X29::inf(), lane, 8);
+        if (lane == 0) partB[0] = sufb;  // lane 0 alone reads it back below
+        y = wave_sum29_n(lane == 0 || lane >= W ? G1X29::inf() : sufb, 8);
+      }
 #pragma unroll 1
       for (int i = 0; i < 6; i++) y = x29_dbl(y);
-      acc = x29_add(acc, y);
+      acc = x29_add(wave_sum29_n(lane < W ? partA[lane] : G1X29::inf(), 8), y);
+    } else {
+      acc = partA[0];
     }
     if (t == 0) {
 #pragma unroll 1
       for (int i = 0; i < 6; i++) acc = x29_dbl(acc);
-      acc = x29_add(acc, sum_b);
+      acc = x29_add(acc, partB[0]);
       st_x(out + col, x29_to_r256(x29_add(acc, partC)));
     }
   }
@@ -1030,7 +1193,7 @@ struct MsmGeom {
   uint32_t c, W, nb, T1, TL, chunk, nblk;
   bool big_digits;  // counting sort with 1024-thread workgroups, up to 256 of them per column
   size_t ecap, cap[4], G;
-  size_t o_bh, o_cnt, o_off[4], o_ent, o_list[4], o_dense, o_rows, o_cols, bytes;
+  size_t o_bh, o_cnt, o_off[4], o_ent, o_list[4], o_dense, o_rows, o_cols, o_ctr, bytes;
 };
 static constexpr int MSM_NLEV = 3;  // level 1 + two folding levels, then the per-bucket final
 
@@ -1079,6 +1242,7 @@ static MsmGeom msm_geometry(const amdzk_srs* srs, size_t ncols, size_t len, size
   g.G = g.nb >> 6;
   g.o_rows = take(ncols * g.G * sizeof(G1X29));
   g.o_cols = take(ncols * ((g.G + 63) / 64) * 64 * sizeof(G1X29));
+  g.o_ctr = take(256);
   g.bytes = o;
   return g;
 }
@@ -1108,13 +1272,21 @@ static int msm_group(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const MsmG
   da.ecap = g.ecap;
   da.table_n = (uint32_t)srs->n;
   dim3 dgrid(g.nblk, (unsigned)ncols);
+  const size_t scan_shmem = (16 + (nb + 1 <= SCAN_LDS_WORDS ? (size_t)nb + 1 : 0)) * sizeof(uint32_t);
+  if (scan_shmem > 65536) {
+    static bool scan_attr_set = false;  // per process: the attribute belongs to the function, not to the context
+    if (!scan_attr_set) {
+      ZK_HIP(ctx, hipFuncSetAttribute((const void*)msm_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((16 + SCAN_LDS_WORDS) * sizeof(uint32_t))));
+      scan_attr_set = true;
+    }
+  }
   ZK_TRY(launch_digits<false>(ctx, g.c, da, dgrid, g.big_digits));
   ZK_LAUNCH(ctx, "msm_blk_offsets", msm_blk_offsets_kernel, dim3((nb + 255) / 256, (unsigned)ncols), dim3(256), 0, blk_hist, cnt, nb, g.nblk);
-  ZK_LAUNCH(ctx, "msm_scan", msm_scan_kernel, dim3((unsigned)ncols), dim3(1024), 0, cnt, off[0], nb, 1u, 1);
+  ZK_LAUNCH(ctx, "msm_scan", msm_scan_kernel, dim3((unsigned)ncols), dim3(1024), scan_shmem, cnt, off[0], nb, 1u, 1);
   ZK_TRY(launch_digits<true>(ctx, g.c, da, dgrid, g.big_digits));
   for (int l = 1; l <= MSM_NLEV; l++) {
     const uint32_t T = l == 1 ? g.T1 : g.TL;
-    ZK_LAUNCH(ctx, "msm_scan", msm_scan_kernel, dim3((unsigned)ncols), dim3(1024), 0, off[l - 1], off[l], nb, T, 2);
+    ZK_LAUNCH(ctx, "msm_scan", msm_scan_kernel, dim3((unsigned)ncols), dim3(1024), scan_shmem, off[l - 1], off[l], nb, T, 2);
     AccArgs a;
     a.off_in = off[l - 1];
     a.off_out = off[l];
@@ -1131,18 +1303,26 @@ static int msm_group(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const MsmG
     dim3 grid((unsigned)((threads + MSM_THREADS - 1) / MSM_THREADS), (unsigned)ncols);
     if (l == 1) {
       if (l1_after) ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, l1_after, 0));
-      ZK_LAUNCH(ctx, "msm_accum_l1", msm_accum_seg_kernel<true>, grid, dim3(MSM_THREADS), 0, a);
+      static const int l1_lds = getenv("AMDZK_L1_LDS") ? atoi(getenv("AMDZK_L1_LDS")) : 0;
+      if (l1_lds == 9) {
+        uint32_t* ctr = (uint32_t*)(ws + g.o_ctr);
+        ZK_HIP(ctx, hipMemsetAsync(ctr, 0, sizeof(uint32_t), ctx->stream));
+        const unsigned persist = (unsigned)std::min<size_t>((size_t)grid.x * ncols, (size_t)ctx->num_cu * 3);
+        ZK_LAUNCH(ctx, "msm_accum_l1", msm_accum_l1_persist_kernel, dim3(persist), dim3(MSM_THREADS), 0, a, ctr, grid.x, (uint32_t)ncols);
+      } else if (l1_lds == 4) ZK_LAUNCH(ctx, "msm_accum_l1", msm_accum_l1_lds_kernel<4>, grid, dim3(L1L_THREADS), 0, a);
+      else if (l1_lds == 3) ZK_LAUNCH(ctx, "msm_accum_l1", msm_accum_l1_lds_kernel<3>, grid, dim3(L1L_THREADS), 0, a);
+      else ZK_LAUNCH(ctx, "msm_accum_l1", msm_accum_seg_kernel<true>, grid, dim3(MSM_THREADS), 0, a);
       if (l1_done) ZK_HIP(ctx, hipEventRecord(l1_done, ctx->stream));
     } else {
       ZK_LAUNCH(ctx, "msm_accum_fold", msm_accum_seg_kernel<false>, grid, dim3(MSM_THREADS), 0, a);
     }
   }
+  const unsigned fold_w = (unsigned)((g.G + 63) / 64);  // 1, 2, 4 or 8 (c <= 16): at most 9 wavefronts per workgroup (launch bound 576)
   ZK_LAUNCH(ctx, "msm_accum_final", msm_accum_final_kernel, dim3(nb / 64, (unsigned)ncols), dim3(64), 0, off[MSM_NLEV], nb, list[MSM_NLEV],
             g.cap[MSM_NLEV], dense);
-  ZK_LAUNCH(ctx, "msm_rowcol", msm_rowcol_kernel, dim3((unsigned)(2 * ((g.G + 63) / 64)), (unsigned)ncols), dim3(64 * ROWCOL_WAVES), 0, dense, nb, rows,
-            cols);
-  const unsigned fold_w = (unsigned)((g.G + 63) / 64);  // 1, 2, 4 or 8 (c <= 16): at most 9 wavefronts per workgroup (launch bound 576)
-  ZK_LAUNCH(ctx, "msm_fold", msm_fold_kernel, dim3((unsigned)ncols), dim3(64 * (fold_w + 1)), 0, rows, cols, nb, outp);
+  ZK_LAUNCH(ctx, "msm_rowcol", msm_rowcol_kernel, dim3((unsigned)(2 * ((g.G + 63) / 64)), (unsigned)ncols), dim3(64 * ROWCOL_WAVES), 0, dense, nb, rows, cols);
+  if (fold_w == 1) ZK_LAUNCH(ctx, "msm_fold", msm_fold_kernel<1>, dim3((unsigned)ncols), dim3(128), 0, rows, cols, nb, outp);
+  else ZK_LAUNCH(ctx, "msm_fold", msm_fold_kernel<8>, dim3((unsigned)ncols), dim3(64 * (fold_w + 1)), 0, rows, cols, nb, outp);
   return AMDZK_OK;
 }
 

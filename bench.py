@@ -126,6 +126,30 @@ def launch_ranks(n, argv, worker=None, env_extra=None, timeout=None):
     return rc
 
 
+def cgroup_cpu_max():
+    """(text, cores) of this process's CPU bandwidth limit: cgroup v2 cpu.max, else v1 cfs quota / period; cores None = no limit.
+    (The pool's one-GPU boxes: affinity mask 256 cores, cpu.max "1600000 100000" = 16 cores' worth of time.)"""
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().strip()
+        q, per = txt.split()[:2]
+        return txt, (None if q == "max" else float(q) / float(per))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return "%d %d" % (q, per), (None if q <= 0 else q / per)
+    except (OSError, ValueError):
+        return None, None
+
+
+def usable_cores(affinity_cores):
+    quota = cgroup_cpu_max()[1]
+    if affinity_cores is None:
+        return None
+    return affinity_cores if quota is None else max(1, min(affinity_cores, int(quota + 0.999)))
+
+
 def rank_core_slice(allowed, local_rank, local_world):
     """The cores rank `local_rank` of `local_world` ranks on one host keeps: the r-th contiguous slice of the sorted ids
     the launcher itself may use. Slices are disjoint and cover `allowed`; with fewer cores than ranks the ranks share
@@ -581,7 +605,8 @@ def run_rank(args):
                            "streamed_equals_resident_bytes": stream_equal,
                            "timed_regions": len(regions),
                            "host_cpu_s_per_proof": round(host_cpu_s / steps, 5), "host_threads": min(P, steps) + 1,
-                           "host_cores_allowed": cores_allowed,
+                           "host_cores_allowed": cores_allowed, "host_cgroup_cpu_max": cgroup_cpu_max()[0],
+                           "host_cores_usable": usable_cores(cores_allowed),
                            "host_cores_per_rank": [{"rank": r, "cores": c[0], "first": c[1], "last": c[2]} for r, c in enumerate(rank_cores)],
                            "host_cores_rule": ("rank r keeps the r-th contiguous slice of the launcher's allowed cores (sched_setaffinity before "
                                                "any GPU call)") if core_slice is not None else "the launcher's mask, unchanged",

@@ -421,109 +421,135 @@ def create_proof(pk, instances, advice_values, seed, trace=None, transcript="bla
     """plonk::prover::create_proof for one circuit instance, KZG + SHPLONK + Blake2b, phase 0 only.
     instances[c] = list of public inputs of instance column c; advice_values[c] = n ints (rows past
     the usable range are overwritten by blinding). Returns the proof bytes."""
+    return create_proof_multi(pk, [instances], [advice_values], seed, trace=trace, transcript=transcript, multiopen=multiopen)
+
+
+def create_proof_multi(pk, instances_list, advice_list, seed, trace=None, transcript="blake2b", multiopen="shplonk"):
+    """plonk::prover::create_proof(params, pk, &[circuit; N], &[instances; N], rng, transcript) [UP] — upstream's
+    slices: N instances of the SAME circuit in one proof, phase 0 only. Every per-circuit step loops over the
+    circuits in order (instances absorbed, advice blinded / committed, lookups permuted, permutation products,
+    lookup products), the challenges, the random polynomial and h(X) are shared — h folds the circuits' terms
+    in one Horner chain with y, circuit after circuit —, then the evaluations (advice per circuit, fixed,
+    random, sigma, then per circuit the permutation products and per circuit the lookups) and one multiopen
+    over all queries (per circuit: advice, permutation products, lookups; then fixed, sigma, h, random).
+    With N = 1 this is create_proof, statement for statement."""
     desc, d, n, tau = pk.desc, pk.domain, pk.n, pk.tau
     bf = desc["blinding_factors"]
     usable = n - (bf + 1)
+    N = len(instances_list)
+    assert N >= 1 and len(advice_list) == N
     rng = ChaCha20Rng(seed)
     T = Blake2bWrite() if transcript == "blake2b" else Keccak256Write()
     tr = (lambda *a: trace.append(a)) if trace is not None else (lambda *a: None)
     T.common_scalar(pk.transcript_repr)
+    C = [dict() for _ in range(N)]  # per-circuit state
     # instances
-    inst_values = []
-    for col in instances:
-        assert len(col) <= usable
-        for v in col:
-            T.common_scalar(v)
-        inst_values.append(list(col) + [0] * (n - len(col)))
-    inst_polys = [d.lagrange_to_coeff(v) for v in inst_values]
-    # advice: blind all columns, then draw (unused) commitment blinds, then commit
-    adv = [list(c) for c in advice_values]
-    assert len(adv) == desc["num_advice"] and all(len(c) == n for c in adv)
-    for c in adv:
-        for row in range(usable, n):
-            c[row] = rng.fr()
-    for _ in adv:
-        rng.fr()
-    adv_polys = [d.lagrange_to_coeff(c) for c in adv]
-    for p in adv_polys:
-        cm = commit_tau(p, tau)
-        tr("advice_commit", cm)
-        T.write_point(cm)
+    for ci_, instances in enumerate(instances_list):
+        inst_values = []
+        for col in instances:
+            assert len(col) <= usable
+            for v in col:
+                T.common_scalar(v)
+            inst_values.append(list(col) + [0] * (n - len(col)))
+        C[ci_]["inst_values"] = inst_values
+        C[ci_]["inst_polys"] = [d.lagrange_to_coeff(v) for v in inst_values]
+    # advice: per circuit, blind all columns, then draw (unused) commitment blinds, then commit
+    for ci_, advice_values in enumerate(advice_list):
+        adv = [list(c) for c in advice_values]
+        assert len(adv) == desc["num_advice"] and all(len(c) == n for c in adv)
+        for c in adv:
+            for row in range(usable, n):
+                c[row] = rng.fr()
+        for _ in adv:
+            rng.fr()
+        adv_polys = [d.lagrange_to_coeff(c) for c in adv]
+        for p in adv_polys:
+            cm = commit_tau(p, tau)
+            tr("advice_commit", cm)
+            T.write_point(cm)
+        C[ci_]["adv"], C[ci_]["adv_polys"] = adv, adv_polys
     theta = T.squeeze_challenge()
     tr("theta", theta)
     # lookups: permuted columns
-    lookups = []
-    for lk in desc["lookups"]:
-        def compress(exprs):
-            acc = [0] * n
-            for e in exprs:
-                for row in range(n):
-                    v = evaluate_expr(e, lambda c, r: pk.fixed_values[c][(row + r) % n], lambda c, r: adv[c][(row + r) % n],
-                                      lambda c, r: inst_values[c][(row + r) % n])
-                    acc[row] = (acc[row] * theta + v) % R
-            return acc
-        ci, ct = compress(lk["inputs"]), compress(lk["tables"])
-        a, s = permute_expression_pair(ci, ct, usable, bf, rng)
-        pa = d.lagrange_to_coeff(a)
-        rng.fr()
-        ca = commit_tau(pa, tau)
-        ps = d.lagrange_to_coeff(s)
-        rng.fr()
-        cs_ = commit_tau(ps, tau)
-        T.write_point(ca)
-        T.write_point(cs_)
-        tr("lookup_permuted", ca, cs_)
-        lookups.append({"ci": ci, "ct": ct, "a": a, "s": s, "pa": pa, "ps": ps})
+    for st in C:
+        adv, inst_values = st["adv"], st["inst_values"]
+        lookups = []
+        for lk in desc["lookups"]:
+            def compress(exprs):
+                acc = [0] * n
+                for e in exprs:
+                    for row in range(n):
+                        v = evaluate_expr(e, lambda c, r: pk.fixed_values[c][(row + r) % n], lambda c, r: adv[c][(row + r) % n],
+                                          lambda c, r: inst_values[c][(row + r) % n])
+                        acc[row] = (acc[row] * theta + v) % R
+                return acc
+            ci, ct = compress(lk["inputs"]), compress(lk["tables"])
+            a, s = permute_expression_pair(ci, ct, usable, bf, rng)
+            pa = d.lagrange_to_coeff(a)
+            rng.fr()
+            ca = commit_tau(pa, tau)
+            ps = d.lagrange_to_coeff(s)
+            rng.fr()
+            cs_ = commit_tau(ps, tau)
+            T.write_point(ca)
+            T.write_point(cs_)
+            tr("lookup_permuted", ca, cs_)
+            lookups.append({"ci": ci, "ct": ct, "a": a, "s": s, "pa": pa, "ps": ps})
+        st["lookups"] = lookups
     beta = T.squeeze_challenge()
     gamma = T.squeeze_challenge()
     tr("beta_gamma", beta, gamma)
     # permutation grand products
     cols = desc["permutation_columns"]
     chunk = desc["cs_degree"] - 2
-    colvals = lambda kc: (adv, pk.fixed_values, inst_values)[kc[0]][kc[1]]
-    sets = []
-    deltaomega_col = 1  # delta^j for the running column j
-    last_z = 1
-    for s0 in range(0, len(cols), chunk):
-        cset = cols[s0:s0 + chunk]
-        mod = [1] * n
-        for j, kc in enumerate(cset):
-            vals, sig = colvals(kc), pk.permutations[s0 + j]
-            for row in range(n):
-                mod[row] = mod[row] * (beta * sig[row] + gamma + vals[row]) % R
-        mod = batch_invert(mod)
-        for kc in cset:
-            vals = colvals(kc)
-            dw = deltaomega_col
-            for row in range(n):
-                mod[row] = mod[row] * (dw * beta + gamma + vals[row]) % R
-                dw = dw * d.omega % R
-            deltaomega_col = deltaomega_col * DELTA % R
-        z = [last_z]
-        for row in range(1, n):
-            z.append(z[row - 1] * mod[row - 1] % R)
-        for row in range(n - bf, n):
-            z[row] = rng.fr()
-        last_z = z[n - (bf + 1)]
-        rng.fr()
-        pz = d.lagrange_to_coeff(z)
-        cz = commit_tau(pz, tau)
-        T.write_point(cz)
-        tr("perm_z", cz)
-        sets.append(pz)
+    for st in C:
+        adv, inst_values = st["adv"], st["inst_values"]
+        colvals = lambda kc: (adv, pk.fixed_values, inst_values)[kc[0]][kc[1]]
+        sets = []
+        deltaomega_col = 1  # delta^j for the running column j
+        last_z = 1
+        for s0 in range(0, len(cols), chunk):
+            cset = cols[s0:s0 + chunk]
+            mod = [1] * n
+            for j, kc in enumerate(cset):
+                vals, sig = colvals(kc), pk.permutations[s0 + j]
+                for row in range(n):
+                    mod[row] = mod[row] * (beta * sig[row] + gamma + vals[row]) % R
+            mod = batch_invert(mod)
+            for kc in cset:
+                vals = colvals(kc)
+                dw = deltaomega_col
+                for row in range(n):
+                    mod[row] = mod[row] * (dw * beta + gamma + vals[row]) % R
+                    dw = dw * d.omega % R
+                deltaomega_col = deltaomega_col * DELTA % R
+            z = [last_z]
+            for row in range(1, n):
+                z.append(z[row - 1] * mod[row - 1] % R)
+            for row in range(n - bf, n):
+                z[row] = rng.fr()
+            last_z = z[n - (bf + 1)]
+            rng.fr()
+            pz = d.lagrange_to_coeff(z)
+            cz = commit_tau(pz, tau)
+            T.write_point(cz)
+            tr("perm_z", cz)
+            sets.append(pz)
+        st["sets"] = sets
     # lookup grand products
-    for lk in lookups:
-        den = batch_invert([(beta + lk["a"][i]) * (gamma + lk["s"][i]) % R for i in range(n)])
-        prod = [den[i] * (lk["ci"][i] + beta) % R * (lk["ct"][i] + gamma) % R for i in range(n)]
-        z = [1]
-        for row in range(1, n - bf):
-            z.append(z[row - 1] * prod[row - 1] % R)
-        z += [rng.fr() for _ in range(bf)]
-        rng.fr()
-        lk["pz"] = d.lagrange_to_coeff(z)
-        cz = commit_tau(lk["pz"], tau)
-        T.write_point(cz)
-        tr("lookup_z", cz)
+    for st in C:
+        for lk in st["lookups"]:
+            den = batch_invert([(beta + lk["a"][i]) * (gamma + lk["s"][i]) % R for i in range(n)])
+            prod = [den[i] * (lk["ci"][i] + beta) % R * (lk["ct"][i] + gamma) % R for i in range(n)]
+            z = [1]
+            for row in range(1, n - bf):
+                z.append(z[row - 1] * prod[row - 1] % R)
+            z += [rng.fr() for _ in range(bf)]
+            rng.fr()
+            lk["pz"] = d.lagrange_to_coeff(z)
+            cz = commit_tau(lk["pz"], tau)
+            T.write_point(cz)
+            tr("lookup_z", cz)
     # vanishing: random polynomial
     random_poly = [rng.fr() for _ in range(n)]
     rng.fr()
@@ -532,29 +558,34 @@ def create_proof(pk, instances, advice_values, seed, trace=None, transcript="bla
     tr("random_commit", crand)
     y = T.squeeze_challenge()
     tr("y", y)
-    # quotient: evaluate every constraint on the extended coset, fold with y, divide by Z_H
+    # quotient: evaluate every constraint of every circuit on the extended coset, fold with y, divide by Z_H
     ext = d.extended_len()
     rot_scale = 1 << (d.extended_k - d.k)
     to_ext = d.coeff_to_extended
-    cos = {"fixed": [to_ext(p) for p in pk.fixed_polys], "advice": [to_ext(p) for p in adv_polys],
-           "instance": [to_ext(p) for p in inst_polys], "sigma": [to_ext(p) for p in pk.permutation_polys],
-           "z": [to_ext(p) for p in sets], "lz": [to_ext(l["pz"]) for l in lookups],
-           "la": [to_ext(l["pa"]) for l in lookups], "ls": [to_ext(l["ps"]) for l in lookups]}
+    fixed_cos, sigma_cos = [to_ext(p) for p in pk.fixed_polys], [to_ext(p) for p in pk.permutation_polys]
+    for st in C:
+        st["cos"] = {"fixed": fixed_cos, "advice": [to_ext(p) for p in st["adv_polys"]],
+                     "instance": [to_ext(p) for p in st["inst_polys"]], "sigma": sigma_cos,
+                     "z": [to_ext(p) for p in st["sets"]], "lz": [to_ext(l["pz"]) for l in st["lookups"]],
+                     "la": [to_ext(l["pa"]) for l in st["lookups"]], "ls": [to_ext(l["ps"]) for l in st["lookups"]]}
     l0e, lle, lbe = to_ext(pk.l0_coeff), to_ext(pk.l_last_coeff), to_ext(pk.l_blind_coeff)
     h = []
     for idx in range(ext):
-        def get(kind, i, rot, idx=idx):
-            if kind == "l0":
-                return l0e[idx]
-            if kind == "l_last":
-                return lle[idx]
-            if kind == "l_active":
-                return (1 - (lle[idx] + lbe[idx])) % R
-            return cos[kind][i][(idx + rot * rot_scale) % ext]
-        vals = h_constraints(desc, d, get, beta, gamma, theta, d.coset_point(idx), len(sets), len(lookups))
         acc = 0
-        for v in vals:
-            acc = (acc * y + v) % R
+        for st in C:
+            cos = st["cos"]
+
+            def get(kind, i, rot, idx=idx, cos=cos):
+                if kind == "l0":
+                    return l0e[idx]
+                if kind == "l_last":
+                    return lle[idx]
+                if kind == "l_active":
+                    return (1 - (lle[idx] + lbe[idx])) % R
+                return cos[kind][i][(idx + rot * rot_scale) % ext]
+            vals = h_constraints(desc, d, get, beta, gamma, theta, d.coset_point(idx), len(st["sets"]), len(st["lookups"]))
+            for v in vals:
+                acc = (acc * y + v) % R
         h.append(acc)
     h = d.extended_to_coeff(d.divide_by_vanishing_poly(h))
     pieces = [h[i * n:(i + 1) * n] for i in range(d.quotient_poly_degree)]
@@ -569,8 +600,9 @@ def create_proof(pk, instances, advice_values, seed, trace=None, transcript="bla
     xn = pow(x, n, R)
     # evaluations
     ev = lambda poly, rot: P.eval_polynomial(poly, d.rotate_omega(x, rot))
-    for c, r in desc["advice_queries"]:
-        T.write_scalar(ev(adv_polys[c], r))
+    for st in C:
+        for c, r in desc["advice_queries"]:
+            T.write_scalar(ev(st["adv_polys"][c], r))
     for c, r in desc["fixed_queries"]:
         T.write_scalar(ev(pk.fixed_polys[c], r))
     h_poly = [0] * n
@@ -579,26 +611,31 @@ def create_proof(pk, instances, advice_values, seed, trace=None, transcript="bla
     T.write_scalar(ev(random_poly, 0))
     for p in pk.permutation_polys:
         T.write_scalar(ev(p, 0))
-    for si, pz in enumerate(sets):
-        T.write_scalar(ev(pz, 0))
-        T.write_scalar(ev(pz, 1))
-        if si + 1 < len(sets):
-            T.write_scalar(ev(pz, -(bf + 1)))
-    for lk in lookups:
-        for poly, rot in ((lk["pz"], 0), (lk["pz"], 1), (lk["pa"], 0), (lk["pa"], -1), (lk["ps"], 0)):
-            T.write_scalar(ev(poly, rot))
+    for st in C:
+        sets = st["sets"]
+        for si, pz in enumerate(sets):
+            T.write_scalar(ev(pz, 0))
+            T.write_scalar(ev(pz, 1))
+            if si + 1 < len(sets):
+                T.write_scalar(ev(pz, -(bf + 1)))
+    for st in C:
+        for lk in st["lookups"]:
+            for poly, rot in ((lk["pz"], 0), (lk["pz"], 1), (lk["pa"], 0), (lk["pa"], -1), (lk["ps"], 0)):
+                T.write_scalar(ev(poly, rot))
     # multiopen queries, upstream order. poly identity = python object id
     queries = []
     Qy = lambda poly, rot: queries.append((poly, d.rotate_omega(x, rot)))
-    for c, r in desc["advice_queries"]:
-        Qy(adv_polys[c], r)
-    for pz in sets:
-        Qy(pz, 0)
-        Qy(pz, 1)
-    for pz in reversed(sets[:-1]):
-        Qy(pz, -(bf + 1))
-    for lk in lookups:
-        Qy(lk["pz"], 0); Qy(lk["pa"], 0); Qy(lk["ps"], 0); Qy(lk["pa"], -1); Qy(lk["pz"], 1)
+    for st in C:
+        sets = st["sets"]
+        for c, r in desc["advice_queries"]:
+            Qy(st["adv_polys"][c], r)
+        for pz in sets:
+            Qy(pz, 0)
+            Qy(pz, 1)
+        for pz in reversed(sets[:-1]):
+            Qy(pz, -(bf + 1))
+        for lk in st["lookups"]:
+            Qy(lk["pz"], 0); Qy(lk["pa"], 0); Qy(lk["ps"], 0); Qy(lk["pa"], -1); Qy(lk["pz"], 1)
     for c, r in desc["fixed_queries"]:
         Qy(pk.fixed_polys[c], r)
     for p in pk.permutation_polys:
@@ -789,74 +826,87 @@ def lagrange_basis_at(d, n, rows, x):
 def verify_proof(pk, instances, proof, transcript="blake2b", multiopen="shplonk"):
     """Checks: transcript re-derivation, the vanishing identity at x, and the SHPLONK opening equation
     (in G1, with the known tau standing in for the pairing). Raises AssertionError on failure."""
+    return verify_proof_multi(pk, [instances], proof, transcript=transcript, multiopen=multiopen)
+
+
+def verify_proof_multi(pk, instances_list, proof, transcript="blake2b", multiopen="shplonk"):
+    """plonk::verifier::verify_proof over N instances of the circuit in one proof (the reader of
+    create_proof_multi): the same checks, every per-circuit read in a loop over the circuits."""
     desc, d, n, tau = pk.desc, pk.domain, pk.n, pk.tau
     bf = desc["blinding_factors"]
+    N = len(instances_list)
     T = Blake2bRead(proof) if transcript == "blake2b" else Keccak256Read(proof)
     T.common_scalar(pk.transcript_repr)
-    for col in instances:
-        for v in col:
-            T.common_scalar(v)
-    adv_c = [T.read_point() for _ in range(desc["num_advice"])]
+    for instances in instances_list:
+        for col in instances:
+            for v in col:
+                T.common_scalar(v)
+    adv_c = [[T.read_point() for _ in range(desc["num_advice"])] for _ in range(N)]
     theta = T.squeeze_challenge()
-    lk_c = [(T.read_point(), T.read_point()) for _ in desc["lookups"]]
+    lk_c = [[(T.read_point(), T.read_point()) for _ in desc["lookups"]] for _ in range(N)]
     beta = T.squeeze_challenge()
     gamma = T.squeeze_challenge()
     chunk = desc["cs_degree"] - 2
     ncols = len(desc["permutation_columns"])
     nsets = (ncols + chunk - 1) // chunk
-    z_c = [T.read_point() for _ in range(nsets)]
-    lz_c = [T.read_point() for _ in desc["lookups"]]
+    z_c = [[T.read_point() for _ in range(nsets)] for _ in range(N)]
+    lz_c = [[T.read_point() for _ in desc["lookups"]] for _ in range(N)]
     rand_c = T.read_point()
     y = T.squeeze_challenge()
     h_c = [T.read_point() for _ in range(d.quotient_poly_degree)]
     x = T.squeeze_challenge()
     xn = pow(x, n, R)
-    adv_e = [T.read_scalar() for _ in desc["advice_queries"]]
+    adv_e = [[T.read_scalar() for _ in desc["advice_queries"]] for _ in range(N)]
     fix_e = [T.read_scalar() for _ in desc["fixed_queries"]]
     rand_e = T.read_scalar()
     sig_e = [T.read_scalar() for _ in range(ncols)]
     z_e = []
-    for s in range(nsets):
-        e = {0: T.read_scalar(), 1: T.read_scalar()}
-        if s + 1 < nsets:
-            e[-(bf + 1)] = T.read_scalar()
-        z_e.append(e)
-    lk_e = [{("lz", 0): T.read_scalar(), ("lz", 1): T.read_scalar(), ("la", 0): T.read_scalar(), ("la", -1): T.read_scalar(),
-             ("ls", 0): T.read_scalar()} for _ in desc["lookups"]]
+    for _ in range(N):
+        ze = []
+        for s in range(nsets):
+            e = {0: T.read_scalar(), 1: T.read_scalar()}
+            if s + 1 < nsets:
+                e[-(bf + 1)] = T.read_scalar()
+            ze.append(e)
+        z_e.append(ze)
+    lk_e = [[{("lz", 0): T.read_scalar(), ("lz", 1): T.read_scalar(), ("la", 0): T.read_scalar(), ("la", -1): T.read_scalar(),
+              ("ls", 0): T.read_scalar()} for _ in desc["lookups"]] for _ in range(N)]
     # l_0, l_last, l_blind at x in closed form; instance evaluations from the public inputs
     # (QUERY_INSTANCE = false): sum_i inst[i] * l_i(x * omega^rot)
     lb = lagrange_basis_at(d, n, [0, n - bf - 1] + list(range(n - bf, n)), x)
     l0, l_last = lb[0], lb[n - bf - 1]
     l_blind = sum(lb[i] for i in range(n - bf, n)) % R
-
-    def inst_eval(i, rot):
-        col = instances[i]
-        if not col:
-            return 0
-        basis = lagrange_basis_at(d, n, range(len(col)), d.rotate_omega(x, rot))
-        return sum(v * basis[j] for j, v in enumerate(col)) % R
-    aq = {q: e for q, e in zip([tuple(q) for q in desc["advice_queries"]], adv_e)}
     fq = {q: e for q, e in zip([tuple(q) for q in desc["fixed_queries"]], fix_e)}
-
-    def get(kind, i, rot):
-        if kind == "advice":
-            return aq[(i, rot)]
-        if kind == "fixed":
-            return fq[(i, rot)]
-        if kind == "instance":
-            return inst_eval(i, rot)
-        if kind == "sigma":
-            return sig_e[i]
-        if kind == "z":
-            return z_e[i][rot]
-        if kind in ("lz", "la", "ls"):
-            return lk_e[i][(kind, rot)]
-        return {"l0": l0, "l_last": l_last, "l_active": (1 - (l_last + l_blind)) % R}[kind]
-
-    vals = h_constraints(desc, d, get, beta, gamma, theta, x, nsets, len(desc["lookups"]))
     acc = 0
-    for vv in vals:
-        acc = (acc * y + vv) % R
+    for ci_ in range(N):
+        instances = instances_list[ci_]
+
+        def inst_eval(i, rot, instances=instances):
+            col = instances[i]
+            if not col:
+                return 0
+            basis = lagrange_basis_at(d, n, range(len(col)), d.rotate_omega(x, rot))
+            return sum(v * basis[j] for j, v in enumerate(col)) % R
+        aq = {q: e for q, e in zip([tuple(q) for q in desc["advice_queries"]], adv_e[ci_])}
+
+        def get(kind, i, rot, aq=aq, inst_eval=inst_eval, ci_=ci_):
+            if kind == "advice":
+                return aq[(i, rot)]
+            if kind == "fixed":
+                return fq[(i, rot)]
+            if kind == "instance":
+                return inst_eval(i, rot)
+            if kind == "sigma":
+                return sig_e[i]
+            if kind == "z":
+                return z_e[ci_][i][rot]
+            if kind in ("lz", "la", "ls"):
+                return lk_e[ci_][i][(kind, rot)]
+            return {"l0": l0, "l_last": l_last, "l_active": (1 - (l_last + l_blind)) % R}[kind]
+
+        vals = h_constraints(desc, d, get, beta, gamma, theta, x, nsets, len(desc["lookups"]))
+        for vv in vals:
+            acc = (acc * y + vv) % R
     expected_h = acc * pow(xn - 1, -1, R) % R
     h_commit = None
     for c in reversed(h_c):
@@ -864,18 +914,19 @@ def verify_proof(pk, instances, proof, transcript="blake2b", multiopen="shplonk"
     # queries in the prover's order: (commitment key, point, eval)
     queries = []
     Qv = lambda key, com, rot, e: queries.append((key, com, d.rotate_omega(x, rot), e))
-    for (c, r), e in zip(desc["advice_queries"], adv_e):
-        Qv(("a", c), adv_c[c], r, e)
-    for s in range(nsets):
-        Qv(("z", s), z_c[s], 0, z_e[s][0])
-        Qv(("z", s), z_c[s], 1, z_e[s][1])
-    for s in reversed(range(nsets - 1)):
-        Qv(("z", s), z_c[s], -(bf + 1), z_e[s][-(bf + 1)])
-    for li in range(len(desc["lookups"])):
-        e = lk_e[li]
-        Qv(("lz", li), lz_c[li], 0, e[("lz", 0)]); Qv(("la", li), lk_c[li][0], 0, e[("la", 0)])
-        Qv(("ls", li), lk_c[li][1], 0, e[("ls", 0)]); Qv(("la", li), lk_c[li][0], -1, e[("la", -1)])
-        Qv(("lz", li), lz_c[li], 1, e[("lz", 1)])
+    for ci_ in range(N):
+        for (c, r), e in zip(desc["advice_queries"], adv_e[ci_]):
+            Qv(("a", ci_, c), adv_c[ci_][c], r, e)
+        for s in range(nsets):
+            Qv(("z", ci_, s), z_c[ci_][s], 0, z_e[ci_][s][0])
+            Qv(("z", ci_, s), z_c[ci_][s], 1, z_e[ci_][s][1])
+        for s in reversed(range(nsets - 1)):
+            Qv(("z", ci_, s), z_c[ci_][s], -(bf + 1), z_e[ci_][s][-(bf + 1)])
+        for li in range(len(desc["lookups"])):
+            e = lk_e[ci_][li]
+            Qv(("lz", ci_, li), lz_c[ci_][li], 0, e[("lz", 0)]); Qv(("la", ci_, li), lk_c[ci_][li][0], 0, e[("la", 0)])
+            Qv(("ls", ci_, li), lk_c[ci_][li][1], 0, e[("ls", 0)]); Qv(("la", ci_, li), lk_c[ci_][li][0], -1, e[("la", -1)])
+            Qv(("lz", ci_, li), lz_c[ci_][li], 1, e[("lz", 1)])
     for (c, r), e in zip(desc["fixed_queries"], fix_e):
         Qv(("f", c), pk.fixed_commitments[c], r, e)
     for i in range(ncols):

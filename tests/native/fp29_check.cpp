@@ -308,6 +308,8 @@ int main() {
         r32 = x_add(v32[i], v32[j]);
         r29 = x29_add(v29[i], v29[j]);
       }
+      for (int q = 0; q < 8; q++)
+        if (r29.x.l[q] >> 29 || r29.y.l[q] >> 29 || r29.zz.l[q] >> 29 || r29.zzz.l[q] >> 29) { fails++; printf("limb not normalised (tree)\n"); }
       G1X back = x29_to_r256(r29);
       if (r32.is_inf() != back.is_inf() || (!r32.is_inf() && !eq_aff(x_to_affine(r32), x_to_affine(back)))) {
         fails++;
