@@ -176,6 +176,7 @@ struct amdzk_pk {
   Fr *rnd = nullptr, *hq = nullptr, *hpieces = nullptr, *hpoly = nullptr, *frac = nullptr, *scratch = nullptr, *scan_tmp = nullptr;
   Fr *frac2 = nullptr, *scratch2 = nullptr, *scan_tmp2 = nullptr;  // the lookup products' own scratch: they run beside the permutation products
   Fr *sets_L = nullptr, *sets_N = nullptr, *sets_Q = nullptr, *hx = nullptr;  // SHPLONK buffers
+  size_t sets_Q_pairs = 0;  // (set, point) pairs sets_Q holds n coefficients for
   // Lanes (common.hpp): 0 = the caller's ctx, 1 and 2 = its auxiliary streams. AMDZK_KEYGEN_SERIAL / AMDZK_SERIAL=1
   // keeps everything on the caller's stream (one proof's kernels strictly one after another, as in rounds 1-2).
   bool use_lanes = true;
@@ -230,6 +231,14 @@ struct amdzk_pk {
   Fr** d_outs_pfrac = nullptr;
   Fr** d_outs_lfrac = nullptr;
   std::vector<void*> allocs;
+  // A workspace clone (amdzk_pk_clone_workspace) shares the key material above — columns, cosets, compiled programs,
+  // domain, constant tables — with the key it was made from and owns one more circuit instance's per-proof workspace and
+  // pointer tables: `allocs` holds only what the clone itself allocated.
+  const amdzk_pk* clone_of = nullptr;
+  // create_proof over several circuit instances (amdzk_create_proof_multi): the evaluation / query lists over all of
+  // them, built by the first such proof on this key for a given list of instance keys
+  Multiopen mo_multi;
+  std::vector<const amdzk_pk*> mo_multi_keys;
   std::vector<const Fr*> h_cols_lag, h_cols_ext;  // host copies of the slot tables (program resolution)
   // pinned host staging (bump allocator, reset whenever the stream is known to be idle)
   char* pin = nullptr;
@@ -893,6 +902,127 @@ static int quotient_pieces(amdzk_ctx* ctx, amdzk_pk* pk) {
   return quotient_from_cosets(ctx, pk);
 }
 
+// The per-proof workspace of ONE circuit instance (arenas, lookup / product scratch, multiopen buffers, small staging):
+// what a key owns besides its key material, and all a workspace clone allocates.
+static int alloc_proof_workspace(amdzk_ctx* ctx, amdzk_pk* pk) {
+  const size_t n = pk->n, ext = pk->ext;
+  const uint32_t A = pk->A, I = pk->I, L = pk->L, ns = pk->nsets;
+#define KG_TRY(x) ZK_TRY(x)
+  pk->NP = (size_t)A + I + 2 * L + ns + L;
+  KG_TRY(dalloc(ctx, pk, &pk->P, pk->NP * n));
+  KG_TRY(dalloc(ctx, pk, &pk->PQ, pk->NP * n));
+  KG_TRY(dalloc(ctx, pk, &pk->PC, pk->NP * ext));
+  KG_TRY(dalloc(ctx, pk, &pk->ci, (size_t)L * n));
+  KG_TRY(dalloc(ctx, pk, &pk->ct, (size_t)L * n));
+  KG_TRY(dalloc(ctx, pk, &pk->lk_ts, (size_t)L * n));
+  KG_TRY(dalloc(ctx, pk, &pk->lk_left, (size_t)L * n));
+  KG_TRY(dalloc(ctx, pk, &pk->lk_flags, (size_t)4 * L * (n + 8)));
+  KG_TRY(dalloc(ctx, pk, &pk->d_err, 1));
+  KG_TRY(dalloc(ctx, pk, &pk->rnd, n));
+  KG_TRY(dalloc(ctx, pk, &pk->hq, (size_t)H_PARTS_MAX * ext));  // one h per piece of the cut h(X) program (finalize_limb_program)
+  KG_TRY(dalloc(ctx, pk, &pk->hpieces, (size_t)pk->qdeg * n));
+  KG_TRY(dalloc(ctx, pk, &pk->hpoly, n));
+  const size_t nfrac = std::max<size_t>(std::max<size_t>(ns, L), 1);
+  KG_TRY(dalloc(ctx, pk, &pk->frac, nfrac * n));
+  KG_TRY(dalloc(ctx, pk, &pk->scratch, std::max(nfrac * n, ext)));
+  KG_TRY(dalloc(ctx, pk, &pk->scan_tmp, zk_scan_totals_elems(n, nfrac) + 2 * nfrac + 8));
+  KG_TRY(dalloc(ctx, pk, &pk->frac2, std::max<size_t>(L, 1) * n));
+  KG_TRY(dalloc(ctx, pk, &pk->scratch2, std::max<size_t>(L, 1) * n));
+  KG_TRY(dalloc(ctx, pk, &pk->scan_tmp2, zk_scan_totals_elems(n, std::max<size_t>(L, 1)) + 2 * std::max<size_t>(L, 1) + 8));
+  const size_t max_rsets = pk->max_sets;
+  KG_TRY(dalloc(ctx, pk, &pk->sets_L, max_rsets * n));
+  KG_TRY(dalloc(ctx, pk, &pk->sets_N, max_rsets * n));
+  KG_TRY(dalloc(ctx, pk, &pk->hx, n));
+  pk->small_cap = std::max<size_t>((size_t)pk->NP * (pk->bf + 2) + 4096, 8192);
+  for (int l = 0; l < 3; l++) KG_TRY(dalloc(ctx, pk, &pk->small_l[l], pk->small_cap));
+  pk->small = pk->small_l[0];
+  pk->pin_cap = std::max<size_t>((size_t)8 << 20, 2 * n * 32);
+  if (hipHostMalloc((void**)&pk->pin, pk->pin_cap, hipHostMallocDefault) != hipSuccess) {
+    pk->pin = nullptr;
+    pk->pin_cap = 0;
+  }
+  pk->ptrs_cap = 8192;
+  for (int l = 0; l < 3; l++) {
+    void** pp = nullptr;
+    KG_TRY(dalloc(ctx, pk, &pp, pk->ptrs_cap));
+    pk->ptrs_l[l] = pp;
+  }
+  pk->ptrs = pk->ptrs_l[0];
+
+#undef KG_TRY
+  return AMDZK_OK;
+}
+
+// The slot -> column pointer tables the interpreters read (Lagrange and quotient domain): key columns and this
+// workspace's arenas.
+static int build_column_tables(amdzk_ctx* ctx, amdzk_pk* pk) {
+  const size_t n = pk->n, ext = pk->ext;
+  const uint32_t F = pk->F, A = pk->A, I = pk->I, S = pk->S, L = pk->L, ns = pk->nsets;
+#define KG_TRY(x) ZK_TRY(x)
+  // ---- column pointer tables
+  {
+    std::vector<const Fr*> lag(pk->nslots_lag()), ex(pk->nslots_ext());
+    for (uint32_t i = 0; i < F; i++) lag[pk->sl_fixed(i)] = pk->fixed_lag + (size_t)i * n, ex[i] = pk->fixed_coset + (size_t)i * ext;
+    for (uint32_t i = 0; i < A; i++) lag[pk->sl_adv(i)] = pk->adv() + (size_t)i * n, ex[pk->sl_adv(i)] = pk->PC + (size_t)i * ext;
+    for (uint32_t i = 0; i < I; i++) lag[pk->sl_inst(i)] = pk->inst() + (size_t)i * n, ex[pk->sl_inst(i)] = pk->PC + (size_t)(A + i) * ext;
+    for (uint32_t i = 0; i < S; i++) lag[pk->sl_sigma(i)] = pk->sigma_lag + (size_t)i * n, ex[pk->se_sigma(i)] = pk->sigma_coset + (size_t)i * ext;
+    for (uint32_t i = 0; i < S; i++) lag[pk->sl_dxw(i)] = pk->dxw_lag + (size_t)i * n, ex[pk->se_dx(i)] = pk->dx_coset + (size_t)i * ext;
+    for (uint32_t l = 0; l < L; l++) {
+      lag[pk->sl_ci(l)] = pk->ci + (size_t)l * n;
+      lag[pk->sl_ct(l)] = pk->ct + (size_t)l * n;
+      lag[pk->sl_la(l)] = pk->la() + (size_t)l * n;
+      lag[pk->sl_ls(l)] = pk->ls() + (size_t)l * n;
+      ex[pk->se_la(l)] = pk->PC + (size_t)(A + I + l) * ext;
+      ex[pk->se_ls(l)] = pk->PC + (size_t)(A + I + L + l) * ext;
+      ex[pk->se_zl(l)] = pk->PC + (size_t)(A + I + 2 * L + ns + l) * ext;
+    }
+    for (uint32_t s = 0; s < ns; s++) ex[pk->se_zp(s)] = pk->PC + (size_t)(A + I + 2 * L + s) * ext;
+    lag[pk->sl_omega()] = pk->omega_pow;
+    ex[pk->se_l0()] = pk->l0_c;
+    ex[pk->se_llast()] = pk->llast_c;
+    ex[pk->se_lactive()] = pk->lactive_c;
+    ex[pk->se_x()] = pk->x_coset;
+    pk->h_cols_lag = lag;
+    pk->h_cols_ext = ex;
+    KG_TRY(dalloc(ctx, pk, &pk->d_cols_lag, lag.size()));
+    KG_TRY(dalloc(ctx, pk, &pk->d_cols_ext, ex.size()));
+    KG_TRY(h2d(ctx, pk->d_cols_lag, lag.data(), lag.size() * sizeof(Fr*)));
+    KG_TRY(h2d(ctx, pk->d_cols_ext, ex.data(), ex.size() * sizeof(Fr*)));
+    ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
+  }
+
+#undef KG_TRY
+  return AMDZK_OK;
+}
+
+// Where the Lagrange-domain programs store: compressed lookup inputs / tables, permutation fractions, lookup fractions.
+static int build_output_tables(amdzk_ctx* ctx, amdzk_pk* pk) {
+  const size_t n = pk->n;
+  const uint32_t L = pk->L, ns = pk->nsets;
+  {
+    std::vector<Fr*> outs(2 * L);
+    for (uint32_t l = 0; l < L; l++) outs[2 * l] = pk->ci + (size_t)l * n, outs[2 * l + 1] = pk->ct + (size_t)l * n;
+    ZK_TRY(dalloc(ctx, pk, &pk->d_outs_compress, outs.size()));
+    ZK_TRY(h2d(ctx, pk->d_outs_compress, outs.data(), outs.size() * sizeof(Fr*)));
+    ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
+  }
+  {
+    std::vector<Fr*> outs(2 * ns);
+    for (uint32_t s = 0; s < ns; s++) outs[2 * s] = pk->frac + (size_t)s * n, outs[2 * s + 1] = pk->zp() + (size_t)s * n;
+    ZK_TRY(dalloc(ctx, pk, &pk->d_outs_pfrac, outs.size()));
+    ZK_TRY(h2d(ctx, pk->d_outs_pfrac, outs.data(), outs.size() * sizeof(Fr*)));
+    ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
+  }
+  {
+    std::vector<Fr*> outs(2 * L);
+    for (uint32_t l = 0; l < L; l++) outs[2 * l] = pk->frac2 + (size_t)l * n, outs[2 * l + 1] = pk->zl() + (size_t)l * n;  // frac2: beside the permutation products
+    ZK_TRY(dalloc(ctx, pk, &pk->d_outs_lfrac, outs.size()));
+    ZK_TRY(h2d(ctx, pk->d_outs_lfrac, outs.data(), outs.size() * sizeof(Fr*)));
+    ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
+  }
+  return AMDZK_OK;
+}
+
 extern "C" {
 
 void amdzk_pk_free(amdzk_ctx* ctx, amdzk_pk* pk) {
@@ -901,7 +1031,7 @@ void amdzk_pk_free(amdzk_ctx* ctx, amdzk_pk* pk) {
   if (ctx) zk_host_wait(ctx, ctx->stream);
   for (void* p : pk->allocs) hipFree(p);
   if (pk->pin) hipHostFree(pk->pin);
-  if (pk->dom) amdzk_domain_free(ctx, pk->dom);
+  if (pk->dom && !pk->clone_of) amdzk_domain_free(ctx, pk->dom);
   delete pk;
 }
 
@@ -1012,46 +1142,7 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
   KG_TRY(dalloc(ctx, pk, &pk->omega_pow, n));
   KG_TRY(dalloc(ctx, pk, &pk->dxw_lag, (size_t)S * n));
   KG_TRY(dalloc(ctx, pk, &pk->dx_coset, (size_t)S * ext));
-  pk->NP = (size_t)A + I + 2 * L + ns + L;
-  KG_TRY(dalloc(ctx, pk, &pk->P, pk->NP * n));
-  KG_TRY(dalloc(ctx, pk, &pk->PQ, pk->NP * n));
-  KG_TRY(dalloc(ctx, pk, &pk->PC, pk->NP * ext));
-  KG_TRY(dalloc(ctx, pk, &pk->ci, (size_t)L * n));
-  KG_TRY(dalloc(ctx, pk, &pk->ct, (size_t)L * n));
-  KG_TRY(dalloc(ctx, pk, &pk->lk_ts, (size_t)L * n));
-  KG_TRY(dalloc(ctx, pk, &pk->lk_left, (size_t)L * n));
-  KG_TRY(dalloc(ctx, pk, &pk->lk_flags, (size_t)4 * L * (n + 8)));
-  KG_TRY(dalloc(ctx, pk, &pk->d_err, 1));
-  KG_TRY(dalloc(ctx, pk, &pk->rnd, n));
-  KG_TRY(dalloc(ctx, pk, &pk->hq, (size_t)H_PARTS_MAX * ext));  // one h per piece of the cut h(X) program (finalize_limb_program)
-  KG_TRY(dalloc(ctx, pk, &pk->hpieces, (size_t)pk->qdeg * n));
-  KG_TRY(dalloc(ctx, pk, &pk->hpoly, n));
-  const size_t nfrac = std::max<size_t>(std::max<size_t>(ns, L), 1);
-  KG_TRY(dalloc(ctx, pk, &pk->frac, nfrac * n));
-  KG_TRY(dalloc(ctx, pk, &pk->scratch, std::max(nfrac * n, ext)));
-  KG_TRY(dalloc(ctx, pk, &pk->scan_tmp, zk_scan_totals_elems(n, nfrac) + 2 * nfrac + 8));
-  KG_TRY(dalloc(ctx, pk, &pk->frac2, std::max<size_t>(L, 1) * n));
-  KG_TRY(dalloc(ctx, pk, &pk->scratch2, std::max<size_t>(L, 1) * n));
-  KG_TRY(dalloc(ctx, pk, &pk->scan_tmp2, zk_scan_totals_elems(n, std::max<size_t>(L, 1)) + 2 * std::max<size_t>(L, 1) + 8));
-  const size_t max_rsets = pk->max_sets;
-  KG_TRY(dalloc(ctx, pk, &pk->sets_L, max_rsets * n));
-  KG_TRY(dalloc(ctx, pk, &pk->sets_N, max_rsets * n));
-  KG_TRY(dalloc(ctx, pk, &pk->hx, n));
-  pk->small_cap = std::max<size_t>((size_t)pk->NP * (pk->bf + 2) + 4096, 8192);
-  for (int l = 0; l < 3; l++) KG_TRY(dalloc(ctx, pk, &pk->small_l[l], pk->small_cap));
-  pk->small = pk->small_l[0];
-  pk->pin_cap = std::max<size_t>((size_t)8 << 20, 2 * n * 32);
-  if (hipHostMalloc((void**)&pk->pin, pk->pin_cap, hipHostMallocDefault) != hipSuccess) {
-    pk->pin = nullptr;
-    pk->pin_cap = 0;
-  }
-  pk->ptrs_cap = 8192;
-  for (int l = 0; l < 3; l++) {
-    void** pp = nullptr;
-    KG_TRY(dalloc(ctx, pk, &pp, pk->ptrs_cap));
-    pk->ptrs_l[l] = pp;
-  }
-  pk->ptrs = pk->ptrs_l[0];
+  KG_TRY(alloc_proof_workspace(ctx, pk));
 
   // ---- host-side tables: omega powers, coset points, l0 / l_last / l_blind (Lagrange)
   {
@@ -1150,37 +1241,7 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
     // prog: one - l_last - l_blind, stored into lactive_c. Done with a tiny dedicated program below, after tables exist.
   }
 
-  // ---- column pointer tables
-  {
-    std::vector<const Fr*> lag(pk->nslots_lag()), ex(pk->nslots_ext());
-    for (uint32_t i = 0; i < F; i++) lag[pk->sl_fixed(i)] = pk->fixed_lag + (size_t)i * n, ex[i] = pk->fixed_coset + (size_t)i * ext;
-    for (uint32_t i = 0; i < A; i++) lag[pk->sl_adv(i)] = pk->adv() + (size_t)i * n, ex[pk->sl_adv(i)] = pk->PC + (size_t)i * ext;
-    for (uint32_t i = 0; i < I; i++) lag[pk->sl_inst(i)] = pk->inst() + (size_t)i * n, ex[pk->sl_inst(i)] = pk->PC + (size_t)(A + i) * ext;
-    for (uint32_t i = 0; i < S; i++) lag[pk->sl_sigma(i)] = pk->sigma_lag + (size_t)i * n, ex[pk->se_sigma(i)] = pk->sigma_coset + (size_t)i * ext;
-    for (uint32_t i = 0; i < S; i++) lag[pk->sl_dxw(i)] = pk->dxw_lag + (size_t)i * n, ex[pk->se_dx(i)] = pk->dx_coset + (size_t)i * ext;
-    for (uint32_t l = 0; l < L; l++) {
-      lag[pk->sl_ci(l)] = pk->ci + (size_t)l * n;
-      lag[pk->sl_ct(l)] = pk->ct + (size_t)l * n;
-      lag[pk->sl_la(l)] = pk->la() + (size_t)l * n;
-      lag[pk->sl_ls(l)] = pk->ls() + (size_t)l * n;
-      ex[pk->se_la(l)] = pk->PC + (size_t)(A + I + l) * ext;
-      ex[pk->se_ls(l)] = pk->PC + (size_t)(A + I + L + l) * ext;
-      ex[pk->se_zl(l)] = pk->PC + (size_t)(A + I + 2 * L + ns + l) * ext;
-    }
-    for (uint32_t s = 0; s < ns; s++) ex[pk->se_zp(s)] = pk->PC + (size_t)(A + I + 2 * L + s) * ext;
-    lag[pk->sl_omega()] = pk->omega_pow;
-    ex[pk->se_l0()] = pk->l0_c;
-    ex[pk->se_llast()] = pk->llast_c;
-    ex[pk->se_lactive()] = pk->lactive_c;
-    ex[pk->se_x()] = pk->x_coset;
-    pk->h_cols_lag = lag;
-    pk->h_cols_ext = ex;
-    KG_TRY(dalloc(ctx, pk, &pk->d_cols_lag, lag.size()));
-    KG_TRY(dalloc(ctx, pk, &pk->d_cols_ext, ex.size()));
-    KG_TRY(h2d(ctx, pk->d_cols_lag, lag.data(), lag.size() * sizeof(Fr*)));
-    KG_TRY(h2d(ctx, pk->d_cols_ext, ex.data(), ex.size() * sizeof(Fr*)));
-    ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
-  }
+  KG_TRY(build_column_tables(ctx, pk));
 
   // ---- programs
   auto colkind_slot_lag = [&](std::pair<int, int> kc) { return kc.first == 0 ? pk->sl_adv(kc.second) : kc.first == 1 ? pk->sl_fixed(kc.second) : pk->sl_inst(kc.second); };
@@ -1214,11 +1275,6 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
       }
       e += pk->lookup_shape[l].second;
     }
-    std::vector<Fr*> outs(2 * L);
-    for (uint32_t l = 0; l < L; l++) outs[2 * l] = pk->ci + (size_t)l * n, outs[2 * l + 1] = pk->ct + (size_t)l * n;
-    KG_TRY(dalloc(ctx, pk, &pk->d_outs_compress, outs.size()));
-    KG_TRY(h2d(ctx, pk->d_outs_compress, outs.data(), outs.size() * sizeof(Fr*)));
-    ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   }
   // (2) permutation fractions: den[s] -> frac column s (inverted later), num[s] -> zp column s. Per set: the columns'
   // w_j = (v_j + gamma) / beta stay on the stack and serve both products, prod_j (sigma_j + w_j) and
@@ -1253,11 +1309,6 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
         pr.pop();
       }
     }
-    std::vector<Fr*> outs(2 * ns);
-    for (uint32_t s = 0; s < ns; s++) outs[2 * s] = pk->frac + (size_t)s * n, outs[2 * s + 1] = pk->zp() + (size_t)s * n;
-    KG_TRY(dalloc(ctx, pk, &pk->d_outs_pfrac, outs.size()));
-    KG_TRY(h2d(ctx, pk->d_outs_pfrac, outs.data(), outs.size() * sizeof(Fr*)));
-    ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   }
   // (3) lookup fractions: den = (a'+beta)(s'+gamma) -> frac2[l]; num = (ci+beta)(ct+gamma) -> zl[l]
   {
@@ -1285,11 +1336,6 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
       pr.op(OP_STORE, 2 * l + 1);
       pr.pop();
     }
-    std::vector<Fr*> outs(2 * L);
-    for (uint32_t l = 0; l < L; l++) outs[2 * l] = pk->frac2 + (size_t)l * n, outs[2 * l + 1] = pk->zl() + (size_t)l * n;  // frac2: beside the permutation products
-    KG_TRY(dalloc(ctx, pk, &pk->d_outs_lfrac, outs.size()));
-    KG_TRY(h2d(ctx, pk->d_outs_lfrac, outs.data(), outs.size() * sizeof(Fr*)));
-    ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
   }
   // (4) the h(X) numerator: gates, permutation, lookups — evaluation.rs evaluate_h order
   {
@@ -1402,6 +1448,7 @@ int amdzk_keygen_ex(amdzk_ctx* ctx, const amdzk_srs* srs, const amdzk_circuit* c
     amdzk_pk_free(ctx, pk);
     ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "keygen: more than 255 distinct rotations");
   }
+  KG_TRY(build_output_tables(ctx, pk));
   KG_TRY(dalloc(ctx, pk, &pk->d_consts, pk->consts.size()));
   KG_TRY(h2d(ctx, pk->d_consts, pk->consts.data(), pk->consts.size() * 32));
   KG_TRY(dalloc(ctx, pk, &pk->d_consts261, pk->consts.size()));
@@ -1501,9 +1548,19 @@ int amdzk_pk_commitments(const amdzk_pk* pk, uint64_t* fixed_out /* F x 8 */, ui
 int amdzk_create_proof_ex(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances, const size_t* instance_lens, const void* d_advice,
                           size_t advice_stride, uint64_t rng_seed, int transcript_kind, uint8_t* proof_out, size_t proof_cap,
                           size_t* proof_len);
+static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* const* pks, size_t ncirc, const uint64_t* const* const* instances,
+                             const size_t* const* instance_lens, const void* const* d_advice, size_t advice_stride, RandomSource& rng,
+                             int transcript_kind, uint8_t* proof_out, size_t proof_cap, size_t* proof_len);
+// one circuit instance
 static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances, const size_t* instance_lens, const void* d_advice,
                              size_t advice_stride, RandomSource& rng, int transcript_kind, uint8_t* proof_out, size_t proof_cap,
-                             size_t* proof_len);
+                             size_t* proof_len) {
+  amdzk_pk* const pks[1] = {pk};
+  const uint64_t* const* const inst[1] = {instances};
+  const size_t* const lens[1] = {instance_lens};
+  const void* const adv[1] = {d_advice};
+  return create_proof_impl(ctx, pks, 1, inst, lens, adv, advice_stride, rng, transcript_kind, proof_out, proof_cap, proof_len);
+}
 
 // Number of Fr::random draws one create_proof makes for this key:
 // advice tails + advice blinds, per lookup 2 tails + 2 blinds, per permutation set tail + blind,
@@ -1581,26 +1638,28 @@ int amdzk_create_proof_ex(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* i
   return create_proof_impl(ctx, pk, instances, instance_lens, d_advice, advice_stride, rs, transcript_kind, proof_out, proof_cap, proof_len);
 }
 
-static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances, const size_t* instance_lens, const void* d_advice,
-                             size_t advice_stride, RandomSource& rng, int transcript_kind, uint8_t* proof_out, size_t proof_cap,
-                             size_t* proof_len);
-static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances, const size_t* instance_lens, const void* d_advice,
-                             size_t advice_stride, RandomSource& rng, int transcript_kind, uint8_t* proof_out, size_t proof_cap,
-                             size_t* proof_len) {
+static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* const* pks, size_t ncirc, const uint64_t* const* const* instances_all,
+                             const size_t* const* instance_lens_all, const void* const* d_advice_all, size_t advice_stride, RandomSource& rng,
+                             int transcript_kind, uint8_t* proof_out, size_t proof_cap, size_t* proof_len);
+static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* const* pks, size_t ncirc, const uint64_t* const* const* instances,
+                             const size_t* const* instance_lens, const void* const* d_advice, size_t advice_stride, RandomSource& rng,
+                             int transcript_kind, uint8_t* proof_out, size_t proof_cap, size_t* proof_len) {
   ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
+  if (!pks || ncirc == 0 || !pks[0]) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: no proving key");
+  amdzk_pk* pk = pks[0];
   // AMDZK_MSM_PIPELINE=1 (experiment, off by default): lanes mode also cuts every commitment batch into column groups on
   // two streams with chained level-1 kernels (msm.hip zk_msm_dev_xyzz). Measured slower on both counts — 22.7-25.8 ms
   // against 21.5 for one proof, 66-74 against 74 proofs/s — because a group's small kernels wait for workgroup slots
   // behind the other group's level-1 kernel (profiles/r03b_stream_priorities_and_gating.txt). The caller's ctx gets
   // its own setting back.
   const bool keep_pipeline = ctx->msm_pipeline;
-  if (pk && pk->use_lanes && getenv("AMDZK_MSM_PIPELINE") && atoi(getenv("AMDZK_MSM_PIPELINE")) != 0) {
+  if (pk->use_lanes && ncirc == 1 && getenv("AMDZK_MSM_PIPELINE") && atoi(getenv("AMDZK_MSM_PIPELINE")) != 0) {
     ctx->msm_pipeline = true;
     for (amdzk_ctx* l : ctx->lanes)
       if (l) l->msm_pipeline = true;
   }
-  const int r = create_proof_body(ctx, pk, instances, instance_lens, d_advice, advice_stride, rng, transcript_kind, proof_out, proof_cap, proof_len);
+  const int r = create_proof_body(ctx, pks, ncirc, instances, instance_lens, d_advice, advice_stride, rng, transcript_kind, proof_out, proof_cap, proof_len);
   ctx->msm_pipeline = keep_pipeline;
   if (r != AMDZK_OK) {  // a failed proof may have left work on the lanes: the key's workspace must be quiet before it is used again
     const std::string keep = ctx->err;
@@ -1609,10 +1668,27 @@ static int create_proof_impl(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
   }
   return r;
 }
-static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* instances, const size_t* instance_lens, const void* d_advice,
-                             size_t advice_stride, RandomSource& rng, int transcript_kind, uint8_t* proof_out, size_t proof_cap,
-                             size_t* proof_len) {
-  if (!pk || !proof_len || (pk->A && !d_advice)) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: null argument");
+// One proof over ncirc instances of the circuit (upstream's `circuits: &[C]`, `instances: &[&[&[F]]]`): pks[c] holds
+// instance c's workspace — the key itself for c = 0, workspace clones of it for the others (amdzk_pk_clone_workspace).
+// `pk` below is pks[0]: what the proof has once (transcript representative, random polynomial, h(X), multiopen buffers,
+// staging); every per-circuit step runs in a loop over the instances with `pk` shadowed by that instance's key.
+// Upstream's order (plonk/prover.rs [UP]): instances, advice, lookup permutations, permutation products and lookup
+// products are each written circuit after circuit; the challenges, the random polynomial and h(X) exist once; the
+// evaluations are advice (per circuit), fixed, random, sigma, permutation products (per circuit), lookups (per circuit).
+static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* const* pks, size_t ncirc, const uint64_t* const* const* instances_all,
+                             const size_t* const* instance_lens_all, const void* const* d_advice_all, size_t advice_stride, RandomSource& rng,
+                             int transcript_kind, uint8_t* proof_out, size_t proof_cap, size_t* proof_len) {
+  amdzk_pk* const pk = pks[0];
+  const size_t NC = ncirc;
+  if (!proof_len) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: null argument");
+  for (size_t c = 0; c < NC; c++) {
+    if (!pks[c] || (pk->A && (!d_advice_all || !d_advice_all[c]))) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: null argument (circuit %zu)", c);
+    const amdzk_pk* root_c = pks[c]->clone_of ? pks[c]->clone_of : pks[c];
+    const amdzk_pk* root_0 = pk->clone_of ? pk->clone_of : pk;
+    if (root_c != root_0) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: circuit %zu's key is not the first key or a workspace clone of it", c);
+    for (size_t d = 0; d < c; d++)
+      if (pks[d] == pks[c]) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: circuits %zu and %zu share one workspace", d, c);
+  }
   const size_t n = pk->n;
   const uint32_t F = pk->F, A = pk->A, I = pk->I, S = pk->S, L = pk->L, ns = pk->nsets, bf = pk->bf;
   const size_t usable = n - (bf + 1);
@@ -1642,7 +1718,7 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
   // the arithmetic between two challenges is unordered there too. With AMDZK_KEYGEN_SERIAL, or while per-kernel
   // profiling is on, B = C = M and everything below degenerates to one stream.
   amdzk_ctx *M = ctx, *B = ctx, *C = ctx;
-  if (pk->use_lanes) {
+  if (pk->use_lanes && NC == 1) {  // several instances: one stream (each lane holds one commitment batch's result at a time)
     ZK_TRY(zk_lane(ctx, 0, &B));
     ZK_TRY(zk_lane(ctx, 1, &C));
     B->msm_pipeline = C->msm_pipeline = ctx->msm_pipeline;
@@ -1700,7 +1776,7 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
   // level-1 kernel (both fill the chip: side by side they only stretch each other) and run beside its tail and beside
   // the next phase's latency-bound kernels instead
   static const bool gate_l1 = !(getenv("AMDZK_NTT_AFTER_L1") && atoi(getenv("AMDZK_NTT_AFTER_L1")) == 0);
-  auto transforms_on_B = [&](amdzk_ctx* after, size_t first, size_t count, bool after_l1 = false) -> int {
+  auto transforms_on_B = [&](amdzk_pk* pk, amdzk_ctx* after, size_t first, size_t count, bool after_l1 = false) -> int {
     if (!count) return AMDZK_OK;
     // (behind the WHOLE batch instead — AMDZK_NTT_AFTER_L1=2 in an experiment — measured 19.1-19.8 ms per proof against 18.7-19.1)
     if (after_l1 && gate_l1) ZK_TRY(zk_stream_after_l1(B, after));
@@ -1712,13 +1788,17 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
 
   // 0. vk, instances
   T.common_scalar(pk->transcript_repr);
-  if (I) {  // columns are zero beyond the caller's values: clear on the device, upload only what was given
+  for (size_t ci = 0; ci < NC && I; ci++) {  // columns are zero beyond the caller's values: clear on the device, upload only what was given
+    amdzk_pk* const pk = pks[ci];
+    const uint64_t* const* instances = instances_all ? instances_all[ci] : nullptr;
+    const size_t* instance_lens = instance_lens_all ? instance_lens_all[ci] : nullptr;
     ZK_HIP(ctx, hipMemsetAsync(pk->inst(), 0, (size_t)I * n * 32, ctx->stream));
     std::vector<Fr> iv;
     for (uint32_t c = 0; c < I; c++) {
       const size_t len = instance_lens ? instance_lens[c] : 0;
       if (len > usable) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: instance column %u too long (InstanceTooLarge)", c);
       if (!len) continue;
+      if (!instances || !instances[c]) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: instance column %u is null", c);
       iv.resize(len);
       for (size_t i = 0; i < len; i++) {
         memcpy(iv[i].l, instances[c] + 4 * i, 32);
@@ -1732,8 +1812,9 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
   // The random polynomial of the vanishing argument (step 5 below) depends on nothing but the RNG: its n draws follow
   // all blinding draws, whose number is fixed by the key, so they are taken from that position of the stream now —
   // generated and committed on lane C while M commits the advice columns.
-  const size_t draws_before_random = (size_t)A * (bf + 1) + A + (size_t)L * (2 * (bf + 1) + 2) + (size_t)ns * (bf + 1) + (size_t)L * (bf + 1);
-  Commit cm_rnd, cm_zp, cm_zl;
+  const size_t draws_before_random = NC * ((size_t)A * (bf + 1) + A + (size_t)L * (2 * (bf + 1) + 2) + (size_t)ns * (bf + 1) + (size_t)L * (bf + 1));
+  Commit cm_rnd;
+  std::vector<Commit> cm_zp_all(NC), cm_zl_all(NC);
   {
     ZK_TRY(zk_stream_after(C, M));  // the previous proof on this key may still be reading rnd on M's stream
     if (rng.rng) {
@@ -1747,17 +1828,18 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     ZK_TRY(commit_begin(C, AMDZK_BASIS_G, pk->rnd, 1, cm_rnd));
   }
   // 1. advice: copy in, blind the unusable rows of every column, draw the (unused) blinds, commit
-  if (A) {
-    ZK_HIP(ctx, hipMemcpy2DAsync(pk->adv(), n * 32, d_advice, advice_stride * 32, n * 32, A, hipMemcpyDeviceToDevice, ctx->stream));
-    std::vector<Fr> tail((size_t)A * (bf + 1));
-    for (auto& v : tail) v = rng.fr();
-    for (uint32_t c = 0; c < A; c++) (void)rng.fr();
-    ZK_TRY(blind_rows(M, pk->adv(), A, usable, bf + 1, tail));
-  }
-  {
+  for (size_t ci = 0; ci < NC; ci++) {
+    amdzk_pk* const pk = pks[ci];
+    if (A) {
+      ZK_HIP(ctx, hipMemcpy2DAsync(pk->adv(), n * 32, d_advice_all[ci], advice_stride * 32, n * 32, A, hipMemcpyDeviceToDevice, ctx->stream));
+      std::vector<Fr> tail((size_t)A * (bf + 1));
+      for (auto& v : tail) v = rng.fr();
+      for (uint32_t c = 0; c < A; c++) (void)rng.fr();
+      ZK_TRY(blind_rows(M, pk->adv(), A, usable, bf + 1, tail));
+    }
     Commit cm;
     if (A && !serial && gate_l1) ZK_TRY(commit_begin(M, AMDZK_BASIS_G_LAGRANGE, pk->adv(), A, cm));
-    ZK_TRY(transforms_on_B(M, 0, (size_t)A + I, cm.begun));
+    ZK_TRY(transforms_on_B(pk, M, 0, (size_t)A + I, cm.begun));
     if (A && !cm.begun) ZK_TRY(commit_begin(M, AMDZK_BASIS_G_LAGRANGE, pk->adv(), A, cm));
     ZK_TRY(commit_end(cm));
     ZK_TRY(write_points(cm.pts, "advice"));
@@ -1766,10 +1848,15 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
   tick("advice");
   Fr theta = T.squeeze_challenge();
   trace_fr("theta", theta);
-  pk->consts[pk->c_theta] = theta;
-  ZK_TRY(h2d_staged(ctx, pk, pk->d_consts + pk->c_theta, &pk->consts[pk->c_theta], 32));
+  for (size_t ci = 0; ci < NC; ci++) {
+    amdzk_pk* const pk = pks[ci];
+    pk->consts[pk->c_theta] = theta;
+    ZK_TRY(h2d_staged(ctx, pk, pk->d_consts + pk->c_theta, &pk->consts[pk->c_theta], 32));
+  }
   // 2. lookups: compress, permute (on the device), blind, commit
-  if (L) {
+  amdzk_pk* const pk0 = pk;  // the small staging buffers the lambdas above write are the first key's
+  for (size_t ci = 0; ci < NC && L; ci++) {
+    amdzk_pk* const pk = pks[ci];
     ZK_TRY(run_program(ctx, pk, pk->prog_compress, false, pk->d_outs_compress, nullptr, "expr_lookup_compress"));
     ZK_TRY(d2d(ctx, pk->la(), pk->ci, (size_t)L * n * 32));
     ZK_TRY(zk_permute_expression_pairs(ctx, pk->la(), pk->ct, pk->lk_ts, pk->ls(), pk->lk_left, pk->lk_flags, pk->d_err, L, (uint32_t)n,
@@ -1786,10 +1873,10 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     }
     ZK_TRY(blind_rows(M, pk->la(), L, usable, bf + 1, ta));
     ZK_TRY(upload_small(ts, ta.size()));
-    ZK_TRY(zk_scatter_rows(ctx, pk->ls(), n, usable, pk->small + ta.size(), bf + 1, L));
+    ZK_TRY(zk_scatter_rows(ctx, pk->ls(), n, usable, pk0->small + ta.size(), bf + 1, L));
     Commit cmc;
     if (!serial && gate_l1) ZK_TRY(commit_begin(M, AMDZK_BASIS_G_LAGRANGE, pk->la(), 2 * L, cmc));
-    ZK_TRY(transforms_on_B(M, (size_t)A + I, 2 * (size_t)L, cmc.begun));
+    ZK_TRY(transforms_on_B(pk, M, (size_t)A + I, 2 * (size_t)L, cmc.begun));
     if (!cmc.begun) ZK_TRY(commit_begin(M, AMDZK_BASIS_G_LAGRANGE, pk->la(), 2 * L, cmc));
     ZK_TRY(commit_end(cmc));
     const std::vector<G1Affine>& cm = cmc.pts;
@@ -1803,29 +1890,39 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
   Fr gamma = T.squeeze_challenge();
   trace_fr("beta", beta);
   trace_fr("gamma", gamma);
-  pk->consts[pk->c_beta] = beta;
-  pk->consts[pk->c_gamma] = gamma;
   // the permutation factors are evaluated as beta (sigma + w) and beta (delta^j X + w) with w = (v + gamma) / beta
   if (S && beta.is_zero()) ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "create_proof: the challenge beta is zero (probability 2^-254): the factored permutation terms need 1 / beta");
-  pk->consts[pk->c_betainv] = inv(beta);
-  ZK_TRY(h2d_staged(ctx, pk, pk->d_consts + pk->c_beta, &pk->consts[pk->c_beta], (size_t)(pk->consts.size() - pk->c_beta) * 32));
+  const Fr beta_inv = inv(beta);
+  for (size_t ci = 0; ci < NC; ci++) {
+    amdzk_pk* const pk = pks[ci];
+    pk->consts[pk->c_beta] = beta;
+    pk->consts[pk->c_gamma] = gamma;
+    pk->consts[pk->c_betainv] = beta_inv;
+    ZK_TRY(h2d_staged(ctx, pk, pk->d_consts + pk->c_beta, &pk->consts[pk->c_beta], (size_t)(pk->consts.size() - pk->c_beta) * 32));
+  }
   tick("  perm: challenges+consts");
   // 3. + 4. permutation grand products on M, lookup grand products on C (they depend on beta and gamma only, not on
   // each other). RNG order: the permutation sets' tails and blinds, then the lookups'.
-  std::vector<Fr> tail_p((size_t)ns * bf), tail_l((size_t)L * bf);
-  for (uint32_t s = 0; s < ns; s++) {
-    for (uint32_t i = 0; i < bf; i++) tail_p[(size_t)s * bf + i] = rng.fr();
-    (void)rng.fr();
-  }
-  for (uint32_t l = 0; l < L; l++) {
-    for (uint32_t i = 0; i < bf; i++) tail_l[(size_t)l * bf + i] = rng.fr();
-    (void)rng.fr();
-  }
+  // (Several instances: every instance's permutation products are committed before the first lookup product.)
+  std::vector<std::vector<Fr>> tail_p_all(NC, std::vector<Fr>((size_t)ns * bf)), tail_l_all(NC, std::vector<Fr>((size_t)L * bf));
+  for (size_t ci = 0; ci < NC; ci++)
+    for (uint32_t s = 0; s < ns; s++) {
+      for (uint32_t i = 0; i < bf; i++) tail_p_all[ci][(size_t)s * bf + i] = rng.fr();
+      (void)rng.fr();
+    }
+  for (size_t ci = 0; ci < NC; ci++)
+    for (uint32_t l = 0; l < L; l++) {
+      for (uint32_t i = 0; i < bf; i++) tail_l_all[ci][(size_t)l * bf + i] = rng.fr();
+      (void)rng.fr();
+    }
   // 5. vanishing: the random polynomial's n draws and its blind (generated above from this position of the stream)
   if (rng.rng) rng.rng->skip_blocks(n);
   else rng.used += n;
   (void)rng.fr();
-  if (L) {
+  for (size_t ci = 0; ci < NC && L; ci++) {
+    amdzk_pk* const pk = pks[ci];
+    const std::vector<Fr>& tail_l = tail_l_all[ci];
+    Commit& cm_zl = cm_zl_all[ci];
     ZK_TRY(zk_stream_after(C, M));  // beta, gamma and the permuted columns are in place
     LN_TRY(C, run_program(C, pk, pk->prog_lfrac, false, pk->d_outs_lfrac, nullptr, "expr_lookup_fractions"));
     LN_TRY(C, zk_batch_invert(C, pk->frac2, pk->scratch2, (size_t)L * n));
@@ -1835,11 +1932,14 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     // ... and their commitment, enqueued BEFORE the permutation chain: the lookup chain is the shorter one, so its
     // level-1 kernel runs while M is still in fractions, inversion and scans rather than beside M's own level-1 kernel.
     // (Measured: 18.8-19.3 ms per proof either way — what one lane gains the other loses; kept for the simpler order.)
-    if (serial || !gate_l1) ZK_TRY(transforms_on_B(C, (size_t)A + I + 2 * L + ns, L));
+    if (serial || !gate_l1) ZK_TRY(transforms_on_B(pk, C, (size_t)A + I + 2 * L + ns, L));
     ZK_TRY(commit_begin(C, AMDZK_BASIS_G_LAGRANGE, pk->zl(), L, cm_zl));
-    if (!serial && gate_l1) ZK_TRY(transforms_on_B(C, (size_t)A + I + 2 * L + ns, L, true));
+    if (!serial && gate_l1) ZK_TRY(transforms_on_B(pk, C, (size_t)A + I + 2 * L + ns, L, true));
   }
-  if (ns) {
+  for (size_t ci = 0; ci < NC && ns; ci++) {
+    amdzk_pk* const pk = pks[ci];
+    const std::vector<Fr>& tail_p = tail_p_all[ci];
+    Commit& cm_zp = cm_zp_all[ci];
     ZK_TRY(run_program(ctx, pk, pk->prog_pfrac, false, pk->d_outs_pfrac, nullptr, "expr_perm_fractions"));
     tick("  perm: fractions program");
     ZK_TRY(zk_batch_invert(ctx, pk->frac, pk->scratch, (size_t)ns * n));
@@ -1848,24 +1948,50 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     ZK_TRY(zk_running_product(ctx, pk->zp(), ns, n, n, true, usable, pk->scan_tmp));
     tick("  perm: running product");
     ZK_TRY(blind_rows(M, pk->zp(), ns, n - bf, bf, tail_p));
-    if (serial || !gate_l1) ZK_TRY(transforms_on_B(M, (size_t)A + I + 2 * L, ns));
+    if (serial || !gate_l1) ZK_TRY(transforms_on_B(pk, M, (size_t)A + I + 2 * L, ns));
     ZK_TRY(commit_begin(M, AMDZK_BASIS_G_LAGRANGE, pk->zp(), ns, cm_zp));
   }
-  if (ns && !serial && gate_l1) ZK_TRY(transforms_on_B(M, (size_t)A + I + 2 * L, ns, true));
-  ZK_TRY(commit_end(cm_zp));
-  ZK_TRY(write_points(cm_zp.pts, "perm_z"));
+  if (ns && !serial && gate_l1) ZK_TRY(transforms_on_B(pk, M, (size_t)A + I + 2 * L, ns, true));  // lanes: one instance
+  for (size_t ci = 0; ci < NC; ci++) {
+    ZK_TRY(commit_end(cm_zp_all[ci]));
+    ZK_TRY(write_points(cm_zp_all[ci].pts, "perm_z"));
+  }
   tick("perm_products");
-  ZK_TRY(commit_end(cm_zl));
-  ZK_TRY(write_points(cm_zl.pts, "lookup_z"));
+  for (size_t ci = 0; ci < NC; ci++) {
+    ZK_TRY(commit_end(cm_zl_all[ci]));
+    ZK_TRY(write_points(cm_zl_all[ci].pts, "lookup_z"));
+  }
   tick("lookup_products");
   ZK_TRY(write_points(cm_rnd.pts, "random_poly"));
   Fr y = T.squeeze_challenge();
   trace_fr("y", y);
-  pk->consts[pk->c_y] = y;
-  ZK_TRY(h2d_staged(ctx, pk, pk->d_consts + pk->c_y, &pk->consts[pk->c_y], 32));
+  for (size_t ci = 0; ci < NC; ci++) {
+    amdzk_pk* const pk = pks[ci];
+    pk->consts[pk->c_y] = y;
+    ZK_TRY(h2d_staged(ctx, pk, pk->d_consts + pk->c_y, &pk->consts[pk->c_y], 32));
+  }
   // 6. h(X): every committed column is on the quotient domain once lane B has drained
   ZK_TRY(zk_stream_after(M, B));
-  ZK_TRY(quotient_from_cosets(ctx, pk));  // theta, beta, gamma, delta powers, y are all known by now
+  for (size_t ci = 0; ci < NC; ci++) ZK_TRY(quotient_from_cosets(ctx, pks[ci]));  // theta, beta, gamma, delta powers, y are all known by now
+  if (NC > 1) {
+    // evaluate_h folds the instances' terms in ONE Horner chain with y, instance after instance: with K terms per instance
+    // the numerator is sum_c y^(K (NC - 1 - c)) * numerator_c, and the division by X^n - 1, the interpolation and the cut
+    // into pieces are linear — so the pieces are the same combination of the instances' pieces.
+    std::vector<const Fr*> pp(NC);
+    std::vector<Fr> cf(NC);
+    const Fr yK = pow_u64(y, pk->h_terms);
+    Fr cur = Fr::one();
+    for (size_t ci = NC; ci-- > 0;) {
+      pp[ci] = pks[ci]->hpieces;
+      cf[ci] = cur;
+      cur = mul(cur, yK);
+    }
+    const size_t len = (size_t)pk->qdeg * n;
+    ZK_TRY(h2d_staged(ctx, pk, pk->ptrs, pp.data(), pp.size() * sizeof(Fr*)));
+    ZK_TRY(upload_small(cf, 0));
+    ZK_TRY(zk_lincomb(ctx, (const Fr* const*)pk->ptrs, pk->small, (uint32_t)NC, pk->scratch, len, false));  // scratch holds >= ext >= qdeg * n
+    ZK_TRY(d2d(ctx, pk->hpieces, pk->scratch, len * 32));
+  }
   {
     for (uint32_t i = 0; i < pk->qdeg; i++) (void)rng.fr();  // h_blinds
     std::vector<G1Affine> cm;
@@ -1892,8 +2018,14 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
   }
   // 7. evaluations. One list of (polynomial, rotation) in proof order, then the two extra
   //    evaluations SHPLONK needs (h_poly at x; random at x is already in the list).
-  amdzk_pk::Multiopen& mo = pk->mo;
-  Fr* adv_poly = pk->q_adv();
+  amdzk_pk::Multiopen& mo = NC == 1 ? pk->mo : pk->mo_multi;
+  if (NC > 1) {  // the cached lists name the polynomials of one particular list of instance keys
+    std::vector<const amdzk_pk*> keys(pks, pks + NC);
+    if (keys != pk->mo_multi_keys) {
+      pk->mo_multi = amdzk_pk::Multiopen();
+      pk->mo_multi_keys = keys;
+    }
+  }
   if (!mo.built) {
     auto rot_id = [&](int rot) -> uint32_t {
       for (size_t i = 0; i < mo.rots.size(); i++)
@@ -1905,22 +2037,27 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
       mo.ev.push_back({p, rot});
       mo.ev_rot.push_back(rot_id(rot));
     };
-    for (auto& q : pk->advice_queries) addq(adv_poly + (size_t)q.first * n, q.second);
+    // written evaluations: advice (instance after instance), fixed, random, sigma, permutation products (instance after
+    // instance), lookups (instance after instance)
+    for (size_t ci = 0; ci < NC; ci++)
+      for (auto& q : pk->advice_queries) addq(pks[ci]->q_adv() + (size_t)q.first * n, q.second);
     for (auto& q : pk->fixed_queries) addq(pk->fixed_poly + (size_t)q.first * n, q.second);
     addq(pk->rnd, 0);
     for (uint32_t i = 0; i < S; i++) addq(pk->sigma_poly + (size_t)i * n, 0);
-    for (uint32_t s = 0; s < ns; s++) {
-      addq(pk->q_zp() + (size_t)s * n, 0);
-      addq(pk->q_zp() + (size_t)s * n, 1);
-      if (s + 1 < ns) addq(pk->q_zp() + (size_t)s * n, -(int)(bf + 1));
-    }
-    for (uint32_t l = 0; l < L; l++) {
-      addq(pk->q_zl() + (size_t)l * n, 0);
-      addq(pk->q_zl() + (size_t)l * n, 1);
-      addq(pk->q_la() + (size_t)l * n, 0);
-      addq(pk->q_la() + (size_t)l * n, -1);
-      addq(pk->q_ls() + (size_t)l * n, 0);
-    }
+    for (size_t ci = 0; ci < NC; ci++)
+      for (uint32_t s = 0; s < ns; s++) {
+        addq(pks[ci]->q_zp() + (size_t)s * n, 0);
+        addq(pks[ci]->q_zp() + (size_t)s * n, 1);
+        if (s + 1 < ns) addq(pks[ci]->q_zp() + (size_t)s * n, -(int)(bf + 1));
+      }
+    for (size_t ci = 0; ci < NC; ci++)
+      for (uint32_t l = 0; l < L; l++) {
+        addq(pks[ci]->q_zl() + (size_t)l * n, 0);
+        addq(pks[ci]->q_zl() + (size_t)l * n, 1);
+        addq(pks[ci]->q_la() + (size_t)l * n, 0);
+        addq(pks[ci]->q_la() + (size_t)l * n, -1);
+        addq(pks[ci]->q_ls() + (size_t)l * n, 0);
+      }
     mo.n_written = mo.ev.size();
     addq(pk->hpoly, 0);
     // 8. multiopen queries in upstream order
@@ -1937,18 +2074,22 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
       mo.q_rot.push_back(rot_id(rot));
       mo.q_ev.push_back(it->second);
     };
-    for (auto& q : pk->advice_queries) addpq(adv_poly + (size_t)q.first * n, q.second);
-    for (uint32_t s = 0; s < ns; s++) {
-      addpq(pk->q_zp() + (size_t)s * n, 0);
-      addpq(pk->q_zp() + (size_t)s * n, 1);
-    }
-    for (int s = (int)ns - 2; s >= 0; s--) addpq(pk->q_zp() + (size_t)s * n, -(int)(bf + 1));
-    for (uint32_t l = 0; l < L; l++) {
-      addpq(pk->q_zl() + (size_t)l * n, 0);
-      addpq(pk->q_la() + (size_t)l * n, 0);
-      addpq(pk->q_ls() + (size_t)l * n, 0);
-      addpq(pk->q_la() + (size_t)l * n, -1);
-      addpq(pk->q_zl() + (size_t)l * n, 1);
+    // per instance: advice queries, the permutation argument's openings, the lookups' openings; then what exists once
+    for (size_t ci = 0; ci < NC; ci++) {
+      amdzk_pk* const pk = pks[ci];
+      for (auto& q : pk->advice_queries) addpq(pk->q_adv() + (size_t)q.first * n, q.second);
+      for (uint32_t s = 0; s < ns; s++) {
+        addpq(pk->q_zp() + (size_t)s * n, 0);
+        addpq(pk->q_zp() + (size_t)s * n, 1);
+      }
+      for (int s = (int)ns - 2; s >= 0; s--) addpq(pk->q_zp() + (size_t)s * n, -(int)(bf + 1));
+      for (uint32_t l = 0; l < L; l++) {
+        addpq(pk->q_zl() + (size_t)l * n, 0);
+        addpq(pk->q_la() + (size_t)l * n, 0);
+        addpq(pk->q_ls() + (size_t)l * n, 0);
+        addpq(pk->q_la() + (size_t)l * n, -1);
+        addpq(pk->q_zl() + (size_t)l * n, 1);
+      }
     }
     for (auto& q : pk->fixed_queries) addpq(pk->fixed_poly + (size_t)q.first * n, q.second);
     for (uint32_t i = 0; i < S; i++) addpq(pk->sigma_poly + (size_t)i * n, 0);
@@ -1956,6 +2097,7 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
     addpq(pk->rnd, 0);
     if (missing) {
       mo = amdzk_pk::Multiopen();
+      pk->mo_multi_keys.clear();
       ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: a multiopen query has no evaluation");
     }
     // shplonk construct_intermediate_sets, in terms of rotations: the polynomials with their sets of rotations
@@ -1995,7 +2137,10 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
       mo = amdzk_pk::Multiopen();
       ZK_FAIL(ctx, AMDZK_E_UNSUPPORTED, "create_proof: more than %u rotation sets", pk->max_sets);
     }
-    ZK_TRY(dalloc(ctx, pk, &pk->sets_Q, std::max<size_t>(pairs, 1) * n));
+    if (std::max<size_t>(pairs, 1) > pk->sets_Q_pairs) {
+      ZK_TRY(dalloc(ctx, pk, &pk->sets_Q, std::max<size_t>(pairs, 1) * n));
+      pk->sets_Q_pairs = std::max<size_t>(pairs, 1);
+    }
     mo.built = true;
   }
   // the points x * omega^rot, once per distinct rotation
@@ -2253,6 +2398,81 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const
   (void)F;
   return AMDZK_OK;
 #undef LN_TRY
+}
+
+// One more circuit instance's workspace for `src`'s circuit: a key handle that shares src's key material (fixed and
+// permutation columns in all three forms, the domain, the compiled programs' text, constant lookup tables — read-only
+// during proofs) and owns its own per-proof workspace, pointer tables and uploaded programs (their instructions carry
+// absolute column addresses). What amdzk_create_proof_multi takes for its second, third, ... instance — and, since a
+// clone is a complete key for create_proof, the cheap way to keep several proofs of one circuit in flight: a
+// clone costs the workspace (the arenas), not the key (354 + 354 MiB of permutation cosets at the metric's shape).
+// Free it with amdzk_pk_free BEFORE the key it was made from.
+int amdzk_pk_clone_workspace(amdzk_ctx* ctx, const amdzk_pk* src, amdzk_pk** out) {
+  ZK_ENTER(ctx);
+  if (!ctx) return AMDZK_E_INVALID;
+  if (!src || !out) ZK_FAIL(ctx, AMDZK_E_INVALID, "pk_clone_workspace: null argument");
+  amdzk_pk* pk = new amdzk_pk(*src);
+  pk->clone_of = src->clone_of ? src->clone_of : src;
+  pk->allocs.clear();
+  pk->pin = nullptr;
+  pk->pin_cap = pk->pin_off = 0;
+  pk->mo = amdzk_pk::Multiopen();
+  pk->mo_multi = amdzk_pk::Multiopen();
+  pk->mo_multi_keys.clear();
+  pk->sets_Q = nullptr;
+  pk->sets_Q_pairs = 0;
+  pk->prog_compress.d_instr = pk->prog_pfrac.d_instr = pk->prog_lfrac.d_instr = pk->prog_h.d_instr = nullptr;
+#define CL_TRY(x)                \
+  do {                           \
+    int _r = (x);                \
+    if (_r != AMDZK_OK) {        \
+      amdzk_pk_free(ctx, pk);    \
+      return _r;                 \
+    }                            \
+  } while (0)
+  CL_TRY(alloc_proof_workspace(ctx, pk));
+  CL_TRY(build_column_tables(ctx, pk));
+  CL_TRY(build_output_tables(ctx, pk));
+  CL_TRY(dalloc(ctx, pk, &pk->d_consts, pk->consts.size()));
+  CL_TRY(h2d(ctx, pk->d_consts, pk->consts.data(), pk->consts.size() * 32));
+  CL_TRY(dalloc(ctx, pk, &pk->d_consts261, pk->consts.size()));
+  CL_TRY(dalloc(ctx, pk, &pk->d_ypow, (size_t)std::max<uint32_t>(pk->h_terms, 1)));
+  ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
+  CL_TRY(upload_program(ctx, pk, pk->prog_compress, false));
+  CL_TRY(upload_program(ctx, pk, pk->prog_pfrac, false));
+  CL_TRY(upload_program(ctx, pk, pk->prog_lfrac, false));
+  CL_TRY(upload_program(ctx, pk, pk->prog_h, true));
+  CL_TRY(upload_consts261(ctx, pk));
+  ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
+#undef CL_TRY
+  *out = pk;
+  return AMDZK_OK;
+}
+
+// plonk::create_proof(params, pk, &[circuit; N], &[instances; N], rng, transcript) [UP]: n_circuits instances of the
+// key's circuit in ONE proof. pks[c]: instance c's workspace — pks[0] the key (or a clone), the others workspace clones of
+// the same key, all different. instances[c][col] / instance_lens[c][col] and d_advice[c] as for amdzk_create_proof_ex.
+int amdzk_create_proof_multi(amdzk_ctx* ctx, amdzk_pk* const* pks, size_t n_circuits, const uint64_t* const* const* instances,
+                             const size_t* const* instance_lens, const void* const* d_advice, size_t advice_stride, uint64_t rng_seed,
+                             int transcript_kind, uint8_t* proof_out, size_t proof_cap, size_t* proof_len) {
+  ZK_ENTER(ctx);
+  if (!ctx) return AMDZK_E_INVALID;
+  if (!pks || n_circuits == 0) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof_multi: no circuits");
+  ChaCha20Rng chacha(rng_seed);
+  RandomSource rs;
+  rs.rng = &chacha;
+  return create_proof_impl(ctx, pks, n_circuits, instances, instance_lens, d_advice, advice_stride, rs, transcript_kind, proof_out, proof_cap, proof_len);
+}
+
+// Byte length of the proof amdzk_create_proof_multi writes for n_circuits instances (amdzk_proof_size for one).
+size_t amdzk_proof_size_multi(const amdzk_pk* pk, size_t n_circuits, int format) {
+  if (!pk || n_circuits == 0) return 0;
+  const int transcript_kind = format & 0xff;
+  const size_t openings = (format & AMDZK_MULTIOPEN_GWC) ? opening_point_count(pk) : 2;
+  const size_t points = n_circuits * ((size_t)pk->A + 2 * (size_t)pk->L + pk->nsets + pk->L) + 1 + pk->qdeg + openings;
+  const size_t scalars = n_circuits * (pk->advice_queries.size() + (pk->nsets ? 3 * (size_t)pk->nsets - 1 : 0) + 5 * (size_t)pk->L) +
+                         pk->fixed_queries.size() + 1 + pk->S;
+  return points * (transcript_kind == AMDZK_TRANSCRIPT_KECCAK256_EVM ? 64 : 32) + scalars * 32;
 }
 
 // ---- function-by-function entry points of the PLONK layer: the same kernels create_proof runs,

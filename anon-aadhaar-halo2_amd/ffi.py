@@ -82,6 +82,10 @@ def lib():
         "amdzk_pk_commitments": (i32, [vp, vp, vp]),
         "amdzk_create_proof": (i32, [vp, vp, C.POINTER(vp), C.POINTER(sz), vp, sz, C.c_uint64, vp, sz, C.POINTER(sz)]),
         "amdzk_create_proof_ex": (i32, [vp, vp, C.POINTER(vp), C.POINTER(sz), vp, sz, C.c_uint64, i32, vp, sz, C.POINTER(sz)]),
+        "amdzk_pk_clone_workspace": (i32, [vp, vp, C.POINTER(vp)]),
+        "amdzk_create_proof_multi": (i32, [vp, C.POINTER(vp), sz, C.POINTER(C.POINTER(vp)), C.POINTER(C.POINTER(sz)), C.POINTER(vp), sz, C.c_uint64, i32,
+                                           vp, sz, C.POINTER(sz)]),
+        "amdzk_proof_size_multi": (sz, [vp, sz, i32]),
         "amdzk_proof_random_count": (sz, [vp]),
         "amdzk_proof_size": (sz, [vp, i32]),
         "amdzk_create_proof_scalars": (i32, [vp, vp, C.POINTER(vp), C.POINTER(sz), vp, sz, vp, sz, i32, vp, sz, C.POINTER(sz)]),

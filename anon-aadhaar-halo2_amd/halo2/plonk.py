@@ -345,6 +345,17 @@ class ProvingKey:
         self.h = h
         del keep
 
+    def clone_workspace(self):
+        """amdzk_pk_clone_workspace: a key that shares this key's material and owns one more circuit instance's per-proof
+        workspace — the second, third, ... instance of create_proof_multi, or one more proof of this circuit in flight.
+        Free it before this key."""
+        c = object.__new__(ProvingKey)
+        c.ctx, c.params, c.desc = self.ctx, self.params, self.desc
+        h = C.c_void_p()
+        self.ctx._chk(self.ctx.L.amdzk_pk_clone_workspace(self.ctx.h, self.h, C.byref(h)))
+        c.h = h
+        return c
+
     def commitments(self):
         """(fixed_commitments, permutation_commitments) as (m, 8) uint64 affine points."""
         f = np.zeros((self.desc["num_fixed"], 8), np.uint64)
@@ -404,6 +415,35 @@ def create_proof(ctx, pk, instances, d_advice, seed, advice_stride=None, transcr
     ctx._chk(ctx.L.amdzk_create_proof_ex(ctx.h, pk.h, ptrs, lens, d_advice.ptr if d_advice is not None else None, advice_stride or n,
                                          C.c_uint64(seed), transcript, buf, cap, C.byref(need)))
     return bytes(buf[: need.value])
+
+
+def create_proof_multi(ctx, pks, instances_list, d_advice_list, seed, advice_stride=None, transcript=TRANSCRIPT_BLAKE2B):
+    """plonk::create_proof(params, pk, &[circuit; N], &[instances; N], ChaCha20Rng::seed_from_u64(seed), transcript):
+    N instances of the key's circuit in one proof. pks: the key and N - 1 workspace clones of it
+    (ProvingKey.clone_workspace); instances_list[c]: instance c's columns; d_advice_list[c]: its advice on the device."""
+    N = len(pks)
+    assert N >= 1 and len(instances_list) == N and len(d_advice_list) == N
+    n = 1 << pks[0].desc["k"]
+    keep, inst_pp, lens_pp = [], (C.POINTER(C.c_void_p) * N)(), (C.POINTER(C.c_size_t) * N)()
+    for c, instances in enumerate(instances_list):
+        cols = [np.ascontiguousarray(col, dtype=np.uint64).reshape(-1, 4) for col in instances]
+        ptrs = (C.c_void_p * max(1, len(cols)))(*[col.ctypes.data if col.size else None for col in cols])
+        lens = (C.c_size_t * max(1, len(cols)))(*[col.shape[0] for col in cols])
+        keep += [cols, ptrs, lens]
+        inst_pp[c] = C.cast(ptrs, C.POINTER(C.c_void_p))
+        lens_pp[c] = C.cast(lens, C.POINTER(C.c_size_t))
+    keys = (C.c_void_p * N)(*[pk.h for pk in pks])
+    adv = (C.c_void_p * N)(*[d.ptr if d is not None else None for d in d_advice_list])
+    need = C.c_size_t(0)
+    cap = 1 << 22
+    buf = (C.c_uint8 * cap)()
+    ctx._chk(ctx.L.amdzk_create_proof_multi(ctx.h, keys, N, inst_pp, lens_pp, adv, advice_stride or n, C.c_uint64(seed), transcript, buf, cap,
+                                            C.byref(need)))
+    return bytes(buf[: need.value])
+
+
+def proof_size_multi(ctx, pk, n_circuits, transcript=TRANSCRIPT_BLAKE2B):
+    return int(ctx.L.amdzk_proof_size_multi(pk.h, n_circuits, transcript))
 
 
 def proof_size(ctx, pk, transcript=TRANSCRIPT_BLAKE2B):

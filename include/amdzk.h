@@ -201,7 +201,7 @@ int amdzk_divide_by_vanishing_dev(amdzk_ctx* ctx, const amdzk_domain* dom, void*
 
 /* ---- create_proof: replaces plonk::{keygen_pk, create_proof} [UP] for
  * KZGCommitmentScheme<Bn256> + ProverSHPLONK (or ProverGWC, AMDZK_MULTIOPEN_GWC) + Blake2bWrite/Challenge255
- * (or the EVM transcript), one circuit instance,
+ * (or the EVM transcript), one circuit instance (amdzk_create_proof_multi: several),
  * phase-0 advice. The circuit arrives as plain data: what ConstraintSystem holds after
  * Circuit::configure (/root/reference/src/lib.rs:295-326 etc.) and selector compression.
  *
@@ -270,6 +270,26 @@ int amdzk_create_proof_ex(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* const* i
                           const size_t* instance_lens, const void* d_advice, size_t advice_stride,
                           uint64_t rng_seed, int transcript_kind, uint8_t* proof_out,
                           size_t proof_cap, size_t* proof_len);
+/* ---- several circuit instances in ONE proof: upstream's create_proof(params, pk, &[circuit; N], &[instances; N], rng,
+ * transcript) [UP] takes slices; the reference passes one circuit (/root/reference/src/lib.rs:299-300 uses
+ * phase 0 only; later phases stay out of scope). Per-circuit steps run circuit after circuit in upstream's order — instance
+ * values absorbed, advice blinded and committed, lookups permuted, permutation products, lookup products, then the advice /
+ * permutation / lookup evaluations and openings — while the challenges, the random polynomial and h(X) exist once (h folds the
+ * instances' terms in one chain with y).
+ * A key owns ONE instance's per-proof workspace: amdzk_pk_clone_workspace makes a handle that shares `pk`'s key material
+ * (fixed / permutation columns and cosets, programs, domain) and owns one more workspace. It is a complete key for
+ * amdzk_create_proof* too (the cheap way to several proofs of one circuit in flight). Free clones (amdzk_pk_free) BEFORE
+ * the key they were made from. */
+int amdzk_pk_clone_workspace(amdzk_ctx* ctx, const amdzk_pk* pk, amdzk_pk** out);
+/* pks[c]: instance c's workspace — the key or clones of it, pairwise different, all on this ctx's device.
+ * instances[c][col] / instance_lens[c][col] and d_advice[c] (+ advice_stride) as for amdzk_create_proof_ex; one RNG stream
+ * and one transcript for the whole proof. n_circuits = 1 is amdzk_create_proof_ex. More than one instance runs on the
+ * caller's stream only (no lanes). */
+int amdzk_create_proof_multi(amdzk_ctx* ctx, amdzk_pk* const* pks, size_t n_circuits,
+                             const uint64_t* const* const* instances, const size_t* const* instance_lens,
+                             const void* const* d_advice, size_t advice_stride, uint64_t rng_seed,
+                             int transcript_kind, uint8_t* proof_out, size_t proof_cap, size_t* proof_len);
+size_t amdzk_proof_size_multi(const amdzk_pk* pk, size_t n_circuits, int transcript_kind);
 /* Exact byte length of the proof for this key, transcript and multiopen scheme (transcript_kind as for
  * amdzk_create_proof_ex, including AMDZK_MULTIOPEN_GWC); a function of the circuit shape only. */
 size_t amdzk_proof_size(const amdzk_pk* pk, int transcript_kind);

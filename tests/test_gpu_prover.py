@@ -407,3 +407,50 @@ def test_caller_supplied_randomness_equals_seeded_rng(ctx, pkg, plonk, oracle):
     with pytest.raises(pkg.AmdzkError):
         plonk.create_proof_with_scalars(ctx, pk, inst, d_adv, draws[:-1])
     d_adv.free(); pk.free(); params.free()
+
+
+@pytest.mark.parametrize("k,ncirc,transcript", [(6, 2, "blake2b"), (6, 2, "keccak"), (7, 2, "blake2b"), (6, 3, "blake2b")])
+def test_several_circuit_instances_in_one_proof(ctx, pkg, plonk, oracle, k, ncirc, transcript):
+    """create_proof(params, pk, &[circuit; N], &[instances; N], ..) — upstream's slices: N instances of one
+    circuit, different witnesses and public inputs, in ONE proof: bytes equal to the oracle's create_proof_multi (both
+    transcripts), accepted by its verifier, N = 1 through the same entry point equals create_proof, a clone alone is a
+    complete key, and the order of the instances matters."""
+    small = dict(k=k, num_advice=5, num_lookup_advice=2, lookup_bits=min(5, k - 2), num_spread=2, spread_bits=3)
+    c = circuits.rsa_sha256_shape(plonk, **small)
+    wit = [(c.advice, c.instances)] + [c.witness(300 + j) for j in range(1, ncirc)]
+    for a, i in wit[1:]:
+        circuits.check_satisfied(c, advice=a, instances=i)
+    assert wit[1][0] != wit[0][0]
+    tk = plonk.TRANSCRIPT_BLAKE2B if transcript == "blake2b" else plonk.TRANSCRIPT_KECCAK256_EVM
+    params, pk, d_adv0, inst0 = setup(ctx, pkg, plonk, oracle, c)
+    pks = [pk] + [pk.clone_workspace() for _ in range(1, ncirc)]
+    d_adv, inst = [d_adv0], [inst0]
+    for a, i in wit[1:]:
+        arr = np.stack([zu.ints_to_fr(oracle, col) for col in a])
+        d_adv.append(ctx.alloc(arr.nbytes).upload(arr))
+        inst.append([zu.ints_to_fr(oracle, col) if col else np.zeros((0, 4), np.uint64) for col in i])
+    got = plonk.create_proof_multi(ctx, pks, inst, d_adv, seed=17, transcript=tk)
+    opk = PR.keygen(c.desc, c.fixed, c.assembly.mapping, TAU, transcript_repr=123456789)
+    want = PR.create_proof_multi(opk, [i for _, i in wit], [a for a, _ in wit], seed=17, transcript=transcript)
+    assert len(got) == plonk.proof_size_multi(ctx, pk, ncirc, tk) == len(want)
+    assert got == want
+    assert PR.verify_proof_multi(vk_from_device(pk, c), [i for _, i in wit], got, transcript=transcript)
+    assert plonk.create_proof_multi(ctx, pks, inst, d_adv, seed=17, transcript=tk) == got  # workspaces reused cleanly
+    # one instance through the slice entry point = create_proof; a clone alone is a complete key
+    single = plonk.create_proof(ctx, pk, inst0, d_adv0, seed=17, transcript=tk)
+    assert plonk.create_proof_multi(ctx, [pk], [inst0], [d_adv0], seed=17, transcript=tk) == single
+    assert plonk.create_proof(ctx, pks[1], inst0, d_adv0, seed=17, transcript=tk) == single
+    assert single == PR.create_proof(opk, c.instances, c.advice, seed=17, transcript=transcript)
+    # the instances' order is part of the statement
+    swapped = plonk.create_proof_multi(ctx, pks, inst[::-1], d_adv[::-1], seed=17, transcript=tk)
+    assert swapped != got
+    with pytest.raises(AssertionError):
+        PR.verify_proof_multi(vk_from_device(pk, c), [i for _, i in wit], swapped, transcript=transcript)
+    # the same workspace twice is refused
+    with pytest.raises(pkg.AmdzkError):
+        plonk.create_proof_multi(ctx, [pk, pk], inst[:2], d_adv[:2], seed=17, transcript=tk)
+    for d in d_adv:
+        d.free()
+    for q in pks[1:]:
+        q.free()
+    pk.free(); params.free()
