@@ -771,6 +771,12 @@ __global__ __launch_bounds__(1024) void bitonic_lds_kernel(Fr* data, Fr* data_b,
   // owns (p and p + blockDim.x): consecutive stages of that kind hand data from a wavefront to itself, and LDS executes a
   // wavefront's accesses in order — the workgroup barrier is only needed next to a stage with j >= 128 (57 of the 78 stages
   // of a 4096-key tile run without one). Needs blockDim.x to be a multiple of 64 and pairs p, p + blockDim.x, ... per thread.
+  // The elision below is an argument about 64-lane wavefronts: refuse to build for anything else, and trap a launch whose
+  // workgroup is not whole wavefronts (zk_sort_keys2 launches 64, 128, ..., 1024 threads).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
+#error "bitonic_lds_kernel: the barrier elision between stages with stride <= 64 assumes 64-lane wavefronts (gfx9 family: gfx950)"
+#endif
+  if ((blockDim.x & 63u) || __builtin_amdgcn_wavefrontsize() != 64) __builtin_trap();
   bool prev_wide = true;  // the load phase above wrote across wavefronts
   for (uint32_t k = k_from; k <= k_to; k <<= 1) {
     uint32_t jstart = k >> 1;

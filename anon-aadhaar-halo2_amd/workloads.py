@@ -125,6 +125,9 @@ def rsa_sha256_shape(k=15, seed=7, num_advice=80, num_lookup_advice=16, lookup_b
     used = set()  # every cell takes part in at most one copy, so fixing up a copied-to cell never disturbs another
 
     def free_gate(ci):
+        if ngates <= 0 or sum(1 for (cc, r) in used if cc == ci) >= 4 * ngates:
+            raise ValueError("rsa_sha256_shape: k = %d with %d gate columns has too few gate rows for the layout's copy constraints "
+                             "(it needs 72 free gates, column %d is full): use a larger k or more columns" % (k, num_advice, ci))
         while True:
             g = int(lay.randint(ngates))
             if all((ci, 4 * g + o) not in used for o in range(4)):

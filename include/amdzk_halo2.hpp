@@ -598,6 +598,14 @@ class ProvingKey {
   }
   ProvingKey(const ProvingKey&) = delete;
   ProvingKey& operator=(const ProvingKey&) = delete;
+  // amdzk_pk_clone_workspace: a key sharing this key's material that owns one more circuit instance's per-proof
+  // workspace (the second, third, ... instance of a multi-circuit create_proof, or one more proof in flight). Must not
+  // outlive this key.
+  std::unique_ptr<ProvingKey> clone_workspace() const {
+    std::unique_ptr<ProvingKey> c(new ProvingKey(ctx_, num_fixed_, num_perm_, num_advice_, k_));
+    ctx_.check(amdzk_pk_clone_workspace(ctx_.get(), h_, &c->h_));
+    return c;
+  }
   // VerifyingKey::{fixed_commitments, permutation.commitments}
   void commitments(std::vector<G1Affine>& fixed, std::vector<G1Affine>& permutation) const {
     fixed.assign(num_fixed_, G1Affine{});
@@ -609,6 +617,7 @@ class ProvingKey {
   size_t num_advice() const { return num_advice_; }
 
  private:
+  ProvingKey(const Context& ctx, size_t nf, size_t np, size_t na, uint32_t k) : ctx_(ctx), num_fixed_(nf), num_perm_(np), num_advice_(na), k_(k) {}
   const Context& ctx_;
   size_t num_fixed_, num_perm_, num_advice_;
   uint32_t k_;
@@ -635,6 +644,40 @@ inline std::vector<uint8_t> create_proof(const Context& ctx, const ProvingKey& p
   std::vector<uint8_t> proof(amdzk_proof_size(pk.handle(), format));
   ctx.check(amdzk_create_proof_ex(ctx.get(), pk.handle(), ptrs.data(), lens.data(), d_advice, advice_stride, rng_seed, format,
                                   proof.data(), proof.size(), &need));
+  proof.resize(need);
+  return proof;
+}
+
+// plonk::create_proof(params, pk, &[circuit; N], &[instances; N], rng, transcript): N instances of the key's circuit in
+// ONE proof (upstream's slices). keys[c]: instance c's workspace — the key itself and ProvingKey::clone_workspace() handles,
+// pairwise different; instances[c], d_advice[c] as for one circuit.
+inline std::vector<uint8_t> create_proof(const Context& ctx, const std::vector<const ProvingKey*>& keys,
+                                         const std::vector<std::vector<std::vector<Fr>>>& instances, const std::vector<const void*>& d_advice,
+                                         size_t advice_stride, uint64_t rng_seed, Transcript transcript = Transcript::Blake2b,
+                                         Multiopen multiopen = Multiopen::Shplonk) {
+  const size_t N = keys.size();
+  if (N == 0 || instances.size() != N || d_advice.size() != N) throw Error(AMDZK_E_INVALID, "create_proof: one key, instance set and witness per circuit");
+  const int format = (int)transcript | (int)multiopen;
+  std::vector<amdzk_pk*> pks(N);
+  std::vector<std::vector<const uint64_t*>> ptrs(N);
+  std::vector<std::vector<size_t>> lens(N);
+  std::vector<const uint64_t* const*> pp(N);
+  std::vector<const size_t*> lp(N);
+  for (size_t c = 0; c < N; c++) {
+    pks[c] = keys[c]->handle();
+    ptrs[c].assign(std::max<size_t>(1, instances[c].size()), nullptr);
+    lens[c].assign(std::max<size_t>(1, instances[c].size()), 0);
+    for (size_t i = 0; i < instances[c].size(); i++) {
+      ptrs[c][i] = instances[c][i].empty() ? nullptr : (const uint64_t*)instances[c][i].data();
+      lens[c][i] = instances[c][i].size();
+    }
+    pp[c] = ptrs[c].data();
+    lp[c] = lens[c].data();
+  }
+  size_t need = 0;
+  std::vector<uint8_t> proof(amdzk_proof_size_multi(pks[0], N, format));
+  ctx.check(amdzk_create_proof_multi(ctx.get(), pks.data(), N, pp.data(), lp.data(), d_advice.data(), advice_stride, rng_seed, format, proof.data(),
+                                     proof.size(), &need));
   proof.resize(need);
   return proof;
 }

@@ -250,6 +250,22 @@ static int prove(int argc, char** argv) {
       std::cout << '\n';
     }
   }
+  {  // upstream's slices: the same circuit twice in ONE proof, through the key and a workspace clone of it
+    const size_t n = (size_t)1 << k;
+    std::vector<Fr> flat(std::max<size_t>(1, advice.size()) * n, Fr::zero());
+    for (size_t c = 0; c < advice.size(); c++) std::copy(advice[c].begin(), advice[c].end(), flat.begin() + c * n);
+    void* d = nullptr;
+    ctx.check(amdzk_dev_alloc(ctx.get(), flat.size() * sizeof(Fr), &d));
+    ctx.check(amdzk_dev_upload(ctx.get(), d, flat.data(), flat.size() * sizeof(Fr)));
+    {
+      std::unique_ptr<ProvingKey> pk2 = pk.clone_workspace();
+      std::vector<uint8_t> two = create_proof(ctx, {&pk, pk2.get()}, {instances, instances}, {d, d}, n, seed, tr, mo);
+      std::cout << "multi2 ";
+      for (uint8_t b : two) std::printf("%02x", b);
+      std::cout << '\n';
+    }
+    amdzk_dev_free(ctx.get(), d);
+  }
   // ParamsKZG surface: commit of the first advice column in both bases (checked by the caller)
   std::vector<G1Affine> fc, pc;
   pk.commitments(fc, pc);

@@ -101,6 +101,9 @@ def test_cpp_driven_proof_equals_oracle(exe, plonk, name, tmp_path):
         assert proof == PR.create_proof(opk, c.instances, c.advice, seed=17, transcript=tr, multiopen=mo), (name, fmt)
         assert PR.verify_proof(opk, c.instances, proof, transcript=tr, multiopen=mo)
         assert "commitments %d %d" % (c.cs.num_fixed, len(c.cs.permutation_columns)) in out
+        # upstream's slices through the C++ mirror: the circuit twice in one proof (key + workspace clone)
+        two = bytes.fromhex(out.split("multi2 ")[1].split()[0])
+        assert two == PR.create_proof_multi(opk, [c.instances] * 2, [c.advice] * 2, seed=17, transcript=tr, multiopen=mo), (name, fmt, "two instances")
         # WitnessStream (pinned staging, async upload, fence): same bytes as the resident path, seed by seed
         streamed = [bytes.fromhex(ln.split()[1]) for ln in out.splitlines() if ln.startswith("streamed ")]
         assert len(streamed) == 3 and streamed[0] == proof

@@ -144,6 +144,22 @@ def test_permute_expression_pair(ctx, ar, oracle, name):
     assert zu.fr_array_to_ints(s_got[0]) == s_want + [0] * (n - usable)
 
 
+@pytest.mark.parametrize("n", [1024, 2048, 4096, 8192])
+def test_permute_expression_pair_around_the_sort_tile(ctx, ar, oracle, n):
+    """The bitonic sort keeps a 2048-key tile in LDS and drops the workgroup barrier between stages whose stride is at
+    most 64 (a wavefront then only hands data to itself: csrc/plonk_kernels.hip bitonic_lds_kernel). Sizes just below, at
+    and above the tile — half a tile, one tile, two and four tiles with global passes between them — on the orders that
+    move the most keys: strictly descending input (every compare-exchange swaps), and a saw-tooth with many repeats."""
+    usable = n - 6
+    for name in ("all_distinct", "many_leftovers", "big_values"):
+        inp, tab = MULTISETS[name](usable)
+        pad = [777] * (n - usable)
+        a_want, s_want = ref_permute(inp, tab, usable)
+        a_got, s_got = ar.permute_expression_pair(ctx, [zu.ints_to_fr(oracle, inp + pad)], [zu.ints_to_fr(oracle, tab + pad)], usable)
+        assert zu.fr_array_to_ints(a_got[0])[:usable] == a_want, (name, n)
+        assert zu.fr_array_to_ints(s_got[0])[:usable] == s_want, (name, n)
+
+
 def test_permute_expression_pair_batch_and_failure(ctx, pkg, ar, oracle):
     n, usable = 128, 122
     pairs = [MULTISETS[k](usable) for k in sorted(MULTISETS)]

@@ -409,7 +409,7 @@ def test_caller_supplied_randomness_equals_seeded_rng(ctx, pkg, plonk, oracle):
     d_adv.free(); pk.free(); params.free()
 
 
-@pytest.mark.parametrize("k,ncirc,transcript", [(6, 2, "blake2b"), (6, 2, "keccak"), (7, 2, "blake2b"), (6, 3, "blake2b")])
+@pytest.mark.parametrize("k,ncirc,transcript", [(7, 2, "blake2b"), (7, 2, "keccak"), (8, 2, "blake2b"), (7, 3, "blake2b")])
 def test_several_circuit_instances_in_one_proof(ctx, pkg, plonk, oracle, k, ncirc, transcript):
     """create_proof(params, pk, &[circuit; N], &[instances; N], ..) — upstream's slices: N instances of one
     circuit, different witnesses and public inputs, in ONE proof: bytes equal to the oracle's create_proof_multi (both
