@@ -2443,6 +2443,9 @@ int amdzk_pk_clone_workspace(amdzk_ctx* ctx, const amdzk_pk* src, amdzk_pk** out
   CL_TRY(upload_program(ctx, pk, pk->prog_lfrac, false));
   CL_TRY(upload_program(ctx, pk, pk->prog_h, true));
   CL_TRY(upload_consts261(ctx, pk));
+  // the compressed constant tables (amdzk_pk::lk_const) are written once, at keygen, into the key's ct columns — the
+  // per-proof compression program skips them — so a new workspace starts with a copy
+  if (pk->lk_const) CL_TRY(d2d(ctx, pk->ct, src->ct, (size_t)pk->lk_const * pk->n * 32));
   ZK_HIP(ctx, zk_host_wait(ctx, ctx->stream));
 #undef CL_TRY
   *out = pk;
