@@ -7,11 +7,10 @@ RSA-SHA256 shape of /root/reference/src/lib.rs:263-274,295-326 at k = 15 — 80 
 advice + 16 SHA spread advice columns, 24 lookups, 115 permutation columns -> 58 grand products, degree 4 so
 extended_k = 17 — plus the IdentityCircuit / TimestampCircuit / SquareCircuit columns and gates: 141 advice, 118
 permutation columns; --shape k15 / k18 = the RSA-SHA256 sub-circuit alone; the shapes live in
-anon-aadhaar-halo2_amd/workloads.py), on synthetic satisfying witnesses that are already resident in HBM when the
-timed region starts. Each step draws fresh blinding (seed = step index), takes the next of the
-resident witnesses and recomputes everything: 278 commitments (multi-scalar multiplications, in 8 batches), 274 inverse
-transforms, 274 x 3 coset transforms, the h(X) numerator on 3 cosets of 2^15 rows, 59 + 24 grand products, ~900
-evaluations, SHPLONK. Witness synthesis (the reference's Rust chips) and keygen are
+anon-aadhaar-halo2_amd/workloads.py), on synthetic satisfying witnesses. Each step draws fresh blinding
+(seed = step index), takes the next of the rank's witnesses and recomputes everything: 278 commitments (multi-scalar
+multiplications, in 8 batches), 274 inverse transforms, 274 x 3 coset transforms, the h(X) numerator on 3 cosets of 2^15
+rows, 59 + 24 grand products, ~900 evaluations, SHPLONK. Witness synthesis (the reference's Rust chips) and keygen are
 outside the step, as in upstream's own split. The SRS is a real one (g[i] = s^i G, g_lagrange[i] = L_i(s) G, built on
 the device), so the proofs are valid; tests/test_gpu_prover.py verifies this circuit's proof with the oracle's verifier.
 
@@ -26,9 +25,13 @@ those of the MEDIAN region and `config.value_samples` lists them all. `config.ho
 time over that region divided by its proofs (all host threads: the per-proof drivers that block on the GPU), and
 `--host-cores N` confines the rank to N cores before anything touches the GPU (one GPU's share of an 8-GPU host).
 
-After the timed region every rank repeats the steps with one host->device witness upload per proof (pinned memory,
-copy stream, double-buffered per in-flight context: anon-aadhaar-halo2_amd/feeder.py) and the line reports that
-PCIe-inclusive rate next to the resident one (config.pcie_inclusive_proofs_per_s); `value` is always the resident rate.
+What is timed (round 4): the regions run with ONE HOST->DEVICE WITNESS UPLOAD PER PROOF — pinned host memory -> one of the
+context's two device buffers on its copy stream, the next proof's upload under the current proof
+(anon-aadhaar-halo2_amd/feeder.py), the upload for a region's first proofs issued under the previous region's last proofs —
+so every region issues exactly `steps` uploads and the first P witnesses are in HBM when it starts: that is `value`, what
+a caller of create_proof with a freshly synthesized witness gets. The same regions with the witnesses kept resident in HBM
+are config.resident_proofs_per_s (the figure rounds 1-3 called `value`); region 0 of both passes must give the same bytes.
+--no-stream-pass times the resident pass only (profiling).
 """
 import argparse
 import hashlib
