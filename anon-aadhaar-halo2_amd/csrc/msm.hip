@@ -334,12 +334,7 @@ struct AccArgs {
 // lanes idle behind the longest task. FIRST is the hot kernel of the whole prover: a mixed addition (madd-2008-s on
 // 29-bit limbs) is 6 products, 2 squares and one two-product reduction (y3 = r (q - x3) - y1 ppp, f29_mul2) — 1,539
 // multiply-adds — on a window-table point (packed canonical, radix 2^261).
-// STAGE (level 1 with T = 32, the long columns of k >= 19): the workgroup's 256 * 32 entries are first copied into LDS with
-// coalesced loads. A lane walking its own 32 consecutive words keeps one 128-byte line per lane alive for 32 additions
-// — 64 lines per wavefront, 12 wavefronts per compute unit, three times the vector L1 — and level 1 of a 2^22-point MSM
-// took 5.2 ms at T1 = 32 against 4.7 at T1 = 12 for the same additions (profiles/r04a_*).
-constexpr uint32_t STAGE_T = 32;
-template <bool FIRST, bool STAGE = false>
+template <bool FIRST>
 __global__ __launch_bounds__(MSM_THREADS) void msm_accum_seg_kernel(AccArgs a) {
   const uint32_t col = blockIdx.y;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -347,14 +342,6 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_accum_seg_kernel(AccArgs a) {
   const uint32_t* off_out = a.off_out + (size_t)col * (a.nb + 1);
   const uint32_t total = off_in[a.nb];
   const uint32_t start = t * a.T;
-  __shared__ uint32_t stage[STAGE ? MSM_THREADS * (STAGE_T + 1) : 1];
-  if (STAGE) {  // row stride 33 words: lane l reads word l * 33 + i — conflict-free
-    const uint32_t blk0 = blockIdx.x * MSM_THREADS * STAGE_T;
-    const uint32_t* src = a.entries + (size_t)col * a.ecap;
-    for (uint32_t j = threadIdx.x; j < MSM_THREADS * STAGE_T && blk0 + j < total; j += MSM_THREADS)
-      stage[(j >> 5) * (STAGE_T + 1) + (j & 31)] = src[blk0 + j];
-    __syncthreads();
-  }
   if (start >= total) return;
   const uint32_t end = min(start + a.T, total);
   uint32_t lo = 0, hi = a.nb;  // largest b with off_in[b] <= start: the non-empty bucket holding `start`
@@ -377,7 +364,7 @@ __global__ __launch_bounds__(MSM_THREADS) void msm_accum_seg_kernel(AccArgs a) {
       } while (e >= b_end);
     }
     if (FIRST) {
-      const uint32_t id = STAGE ? stage[threadIdx.x * (STAGE_T + 1) + (e - start)] : ent[e];
+      const uint32_t id = ent[e];
       G1Affine p = ld_aff(a.table + (id & 0x7fffffffu));
       const bool p_inf = p.is_inf();
       if (id >> 31) p.y = neg(p.y);  // negating a canonical value does not depend on the Montgomery radix
@@ -596,7 +583,7 @@ __device__ __forceinline__ Fq shfl_xor_fq(const Fq& v, int m) {
 // Final level: one lane per bucket folds whatever is left and writes the dense bucket array. A bucket
 // that still holds more than FINAL_SERIAL partial sums (a witness column where one value dominates)
 // is finished by the whole wavefront: lanes take strided shares, then a shuffle-tree sum.
-constexpr uint32_t FINAL_SERIAL = 8;
+constexpr uint32_t FINAL_SERIAL = 6;
 __global__ __launch_bounds__(64) void msm_accum_final_kernel(const uint32_t* off_in_all, uint32_t nb, const G1X29* in_list, size_t in_cap,
                                                              G1X29* dense) {
   const uint32_t col = blockIdx.y, lane = threadIdx.x;
@@ -1233,18 +1220,18 @@ static MsmGeom msm_geometry(const amdzk_srs* srs, size_t ncols, size_t len, size
   if (const char* e = getenv("AMDZK_MSM_T1")) g.T1 = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : g.T1;
   g.TL = 6;  // 4 / 6 / 8 / 12 / 16 prove at the same rate (76.7-78.0 proofs/s); 6 has the shortest proof (profiles/r02j_msm_task_size.txt)
   if (const char* e = getenv("AMDZK_MSM_TL")) g.TL = (uint32_t)atoi(e) > 1 ? (uint32_t)atoi(e) : g.TL;
-  // Folding levels. A bucket holds len * W / nb entries on average (160 at k = 15 whatever the scalars: fewer for witness
-  // columns), i.e. that / T1 partial sums after level 1; the final kernel adds up to FINAL_SERIAL of them per lane and
-  // hands longer lists to the whole wavefront. ONE fold of TL = max(6, partials / 4) leaves about 5 per bucket — enough up
-  // to ~24 partial sums per bucket (every proof-sized MSM: 13 at T1 = 12, 40 at T1 = 4 with TL = 10); a second fold was a
-  // launch, a scan and a pass over all partial sums that found one or two per bucket to add (round 4: msm_accum_fold
-  // 1.77 -> ~1.0 ms of a proof's 18.9 ms of kernel time, one latency-bound launch pair less per commitment batch). The
-  // long columns of k >= 19 (2048 entries per bucket, T1 = 32: 64 partial sums) keep two folds of 6. AMDZK_MSM_NLEV=2|3.
-  {
-    const double per_bucket = (double)len * g.W / g.nb / g.T1;
-    g.nlev = per_bucket <= 44.0 ? 2 : 3;
-    if (const char* e = getenv("AMDZK_MSM_NLEV")) g.nlev = atoi(e) == 2 ? 2 : atoi(e) == 3 ? 3 : g.nlev;
-    if (g.nlev == 2 && !getenv("AMDZK_MSM_TL")) g.TL = std::max<uint32_t>(6, (uint32_t)((per_bucket + 3.0) / 4.0));
+  // Folding levels: two (TL = 6) in front of the per-bucket final. ONE fold (AMDZK_MSM_NLEV=2, with TL = max(6, partial
+  // sums per bucket / 4)) was measured in round 4 and is a trap: the AVERAGE bucket of a proof-sized MSM then reaches the
+  // final kernel with ~5 partial sums, but witness columns are skewed — a few hundred buckets per column hold hundreds — and
+  // every such bucket takes the whole wavefront of its 64 neighbours through the cooperative path: msm_accum_final
+  // 0.76 -> 8.9 ms per proof, 79.6 -> 72 proofs/s (profiles/r04d_one_fold_level_ab.txt).
+  g.nlev = MSM_NLEV;
+  if (const char* e = getenv("AMDZK_MSM_NLEV")) {
+    if (atoi(e) == 2) {
+      const double per_bucket = (double)len * g.W / g.nb / g.T1;
+      g.nlev = 2;
+      if (!getenv("AMDZK_MSM_TL")) g.TL = std::max<uint32_t>(6, (uint32_t)((per_bucket + 3.0) / 4.0));
+    }
   }
   g.cap[0] = g.ecap;
   g.cap[1] = g.ecap / g.T1 + g.nb + 1;
@@ -1338,8 +1325,6 @@ static int msm_group(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const MsmG
         ZK_LAUNCH(ctx, "msm_accum_l1", msm_accum_l1_persist_kernel, dim3(persist), dim3(MSM_THREADS), 0, a, ctr, grid.x, (uint32_t)ncols);
       } else if (l1_lds == 4) ZK_LAUNCH(ctx, "msm_accum_l1", msm_accum_l1_lds_kernel<4>, grid, dim3(L1L_THREADS), 0, a);
       else if (l1_lds == 3) ZK_LAUNCH(ctx, "msm_accum_l1", msm_accum_l1_lds_kernel<3>, grid, dim3(L1L_THREADS), 0, a);
-      else if (T == STAGE_T && !(getenv("AMDZK_L1_STAGE") && atoi(getenv("AMDZK_L1_STAGE")) == 0))
-        ZK_LAUNCH(ctx, "msm_accum_l1", (msm_accum_seg_kernel<true, true>), grid, dim3(MSM_THREADS), 0, a);
       else ZK_LAUNCH(ctx, "msm_accum_l1", msm_accum_seg_kernel<true>, grid, dim3(MSM_THREADS), 0, a);
       if (l1_done) ZK_HIP(ctx, hipEventRecord(l1_done, ctx->stream));
     } else {
