@@ -114,3 +114,20 @@ def test_integration_md_lists_every_environment_variable_the_library_reads():
     assert used, "no getenv found: the pattern is stale"
     assert used - listed == set(), "undocumented: %s" % sorted(used - listed)
     assert listed - used - flags == set(), "documented but not read: %s" % sorted(listed - used - flags)
+
+
+def test_library_is_stamped_with_its_kernel_sources(pkg):
+    """amdzk_build_info() carries the hash of the comment-stripped kernel sources + Makefile the binary was built from
+    (csrc/Makefile -> build_stamp.h, tools/src_hash.py); it is bench.kernel_src_hash() of this tree — which is how bench.py
+    refuses a stale libamdzk.so that travelled with a snapshot — and a comment edit does not change it."""
+    import bench
+    info = pkg.build_info()
+    assert info["arch"] == "gfx950" and info["abi"] == pkg.lib().amdzk_version() >= 1001
+    assert info["src"] == bench.kernel_src_hash(), "libamdzk.so is stale: rebuild (python -c 'import __graft_entry__ as g; g.build()')"
+    assert bench.strip_comments("int a; // x\n/* y */ int  b;") == bench.strip_comments("int a;\nint b; // other comment")
+
+    class FakePkg:
+        def build_info(self):
+            return {"src": "0123456789abcdef"}
+    with pytest.raises(SystemExit):
+        bench.check_library_stamp(FakePkg())
