@@ -341,10 +341,17 @@ __global__ __launch_bounds__(EXPR_THREADS) void expr_eval_limbs_kernel(ExprArgs 
 struct ChaChaKey {
   uint32_t k[8];
 };
-__global__ __launch_bounds__(256) void chacha20_fr_random_kernel(Fr* out, size_t n, ChaChaKey key, uint64_t counter0, Fr r3) {
+// Draw i of the launch is key-stream block counter0 + (i / cnt) * draw_stride + i % cnt and lands at
+// out[(i / cnt) * out_stride + i % cnt]: cnt = n, strides 0 = n consecutive draws into n consecutive elements (the random
+// polynomial); cnt = blinding rows per column, draw_stride = draws per column in upstream's order (tails, then the unused
+// commitment blinds), out_stride = the column stride = the blinding tails of a batch of columns written in place.
+__global__ __launch_bounds__(256) void chacha20_fr_random_kernel(Fr* out, size_t n, ChaChaKey key, uint64_t counter0, Fr r3, uint32_t cnt,
+                                                                 uint32_t draw_stride, size_t out_stride) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint64_t ctr = counter0 + i;
+  const size_t grp = i / cnt, r = i % cnt;
+  const uint64_t ctr = counter0 + grp * draw_stride + r;
+  out += grp * out_stride + r - i;  // out + i below = the element this draw belongs to
   uint32_t c[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key.k[0], key.k[1], key.k[2], key.k[3], key.k[4], key.k[5], key.k[6], key.k[7],
                     (uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
   uint32_t x[16];
@@ -938,7 +945,20 @@ int zk_expr_eval_limbs(amdzk_ctx* ctx, const ExprArgs& a, uint32_t depth, const 
 int zk_chacha20_fr_random(amdzk_ctx* ctx, Fr* d_out, size_t n, const uint32_t key[8], uint64_t counter0, const Fr& r3) {
   ChaChaKey k;
   memcpy(k.k, key, sizeof(k.k));
-  if (n) ZK_LAUNCH(ctx, "chacha20_fr_random", chacha20_fr_random_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_out, n, k, counter0, r3);
+  if (n) ZK_LAUNCH(ctx, "chacha20_fr_random", chacha20_fr_random_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_out, n, k, counter0, r3,
+                   (uint32_t)std::min<size_t>(n, 0xffffffffu), 0u, (size_t)0);
+  return AMDZK_OK;
+}
+
+// The blinding tails of ncols columns drawn where they belong: column c (at d_cols + c * col_stride) gets draws
+// counter0 + c * draw_stride + [0, cnt) of the ChaCha20 stream into rows [row0, row0 + cnt).
+int zk_chacha20_blind_rows(amdzk_ctx* ctx, Fr* d_cols, size_t col_stride, size_t row0, uint32_t cnt, uint32_t ncols, const uint32_t key[8],
+                           uint64_t counter0, uint32_t draw_stride, const Fr& r3) {
+  ChaChaKey k;
+  memcpy(k.k, key, sizeof(k.k));
+  const size_t total = (size_t)cnt * ncols;
+  if (total) ZK_LAUNCH(ctx, "chacha20_blind_rows", chacha20_fr_random_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, d_cols + row0, total, k,
+                       counter0, r3, cnt, draw_stride, col_stride);
   return AMDZK_OK;
 }
 

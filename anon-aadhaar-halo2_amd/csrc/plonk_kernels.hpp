@@ -82,6 +82,8 @@ int zk_expr_eval(amdzk_ctx* ctx, const ExprArgs& a, uint32_t depth, const char* 
 int zk_expr_eval_limbs(amdzk_ctx* ctx, const ExprArgs& a, uint32_t depth, const char* name);
 // d_out[i] = Fr::random of ChaCha20 block counter0 + i under `key` (rand_chacha's ChaCha20Rng, halo2curves' from_u512)
 int zk_chacha20_fr_random(amdzk_ctx* ctx, bn254::Fr* d_out, size_t n, const uint32_t key[8], uint64_t counter0, const bn254::Fr& r3);
+int zk_chacha20_blind_rows(amdzk_ctx* ctx, bn254::Fr* d_cols, size_t col_stride, size_t row0, uint32_t cnt, uint32_t ncols, const uint32_t key[8],
+                           uint64_t counter0, uint32_t draw_stride, const bn254::Fr& r3);
 int zk_batch_invert(amdzk_ctx* ctx, bn254::Fr* d_a, bn254::Fr* d_scratch, size_t total);
 int zk_mul_elem(amdzk_ctx* ctx, bn254::Fr* d_a, const bn254::Fr* d_b, size_t total);
 size_t zk_scan_totals_elems(size_t n, size_t ncols);

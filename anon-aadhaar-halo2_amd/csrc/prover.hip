@@ -211,6 +211,7 @@ struct amdzk_pk {
   // its bucket reduction and lane B's transforms: 18.0-18.2 ms against 17.6-17.95.)
   uint32_t* lk_flags = nullptr;              // [4][L][n+8]
   int* d_err = nullptr;
+  int* h_err = nullptr;                      // pinned: where create_proof reads d_err (the first word of `pin`'s tail block)
   // misc small device buffers (blinding uploads, points, evals, coefs) and pointer-table scratch, one slice per lane:
   // a slice is reused in stream order by the lane that owns it
   Fr* small_l[3] = {nullptr, nullptr, nullptr};
@@ -937,10 +938,12 @@ static int alloc_proof_workspace(amdzk_ctx* ctx, amdzk_pk* pk) {
   for (int l = 0; l < 3; l++) KG_TRY(dalloc(ctx, pk, &pk->small_l[l], pk->small_cap));
   pk->small = pk->small_l[0];
   pk->pin_cap = std::max<size_t>((size_t)8 << 20, 2 * n * 32);
-  if (hipHostMalloc((void**)&pk->pin, pk->pin_cap, hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc((void**)&pk->pin, pk->pin_cap + 64, hipHostMallocDefault) != hipSuccess) {
     pk->pin = nullptr;
     pk->pin_cap = 0;
+    ZK_FAIL(ctx, AMDZK_E_NOMEM, "prover: hipHostMalloc of the pinned staging area failed");
   }
+  pk->h_err = (int*)(pk->pin + pk->pin_cap);  // behind the staging ring
   pk->ptrs_cap = 8192;
   for (int l = 0; l < 3; l++) {
     void** pp = nullptr;
@@ -1813,6 +1816,21 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* const* pks, size_t ncirc,
   // all blinding draws, whose number is fixed by the key, so they are taken from that position of the stream now —
   // generated and committed on lane C while M commits the advice columns.
   const size_t draws_before_random = NC * ((size_t)A * (bf + 1) + A + (size_t)L * (2 * (bf + 1) + 2) + (size_t)ns * (bf + 1) + (size_t)L * (bf + 1));
+  // With the seeded ChaCha20Rng every Fr::random is one key-stream block, draw j = block ctr0 + j, and WHICH draw blinds
+  // which cell is fixed by the key: the blinding tails are generated on the device straight into their rows
+  // (chacha20_blind_rows, like the random polynomial) and the host only moves its counter past them — it used to draw
+  // ~1,800 scalars per proof at 0.3 us each, a third of them in front of the proof's first kernel. A caller's own
+  // RngCore (pre-drawn scalars) keeps the host path. Draw positions, upstream's order:
+  //   advice of instance c: A (bf + 1) tails, column-major, then A blinds;  then per instance and lookup: bf + 1 tails
+  //   of A', bf + 1 of S', two blinds;  then per instance and permutation set bf tails + a blind;  then per instance and
+  //   lookup product bf tails + a blind;  then the random polynomial.
+  const uint64_t ctr0 = rng.rng ? rng.rng->block_counter() : 0;
+  const size_t per_adv = (size_t)A * (bf + 1) + A, per_lk = (size_t)L * (2 * (bf + 1) + 2), per_pz = (size_t)ns * (bf + 1), per_lz = (size_t)L * (bf + 1);
+  const size_t base_lk = NC * per_adv, base_pz = base_lk + NC * per_lk, base_lz = base_pz + NC * per_pz;
+  auto blind_dev = [&](amdzk_ctx* l, Fr* d_cols, uint32_t ncols, size_t row0, uint32_t cnt, size_t first_draw, uint32_t draw_stride) -> int {
+    LN_TRY(l, zk_chacha20_blind_rows(l, d_cols, n, row0, cnt, ncols, rng.rng->key(), ctr0 + first_draw, draw_stride, zkhost::fr_r3()));
+    return AMDZK_OK;
+  };
   Commit cm_rnd;
   std::vector<Commit> cm_zp_all(NC), cm_zl_all(NC);
   {
@@ -1832,10 +1850,15 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* const* pks, size_t ncirc,
     amdzk_pk* const pk = pks[ci];
     if (A) {
       ZK_HIP(ctx, hipMemcpy2DAsync(pk->adv(), n * 32, d_advice_all[ci], advice_stride * 32, n * 32, A, hipMemcpyDeviceToDevice, ctx->stream));
-      std::vector<Fr> tail((size_t)A * (bf + 1));
-      for (auto& v : tail) v = rng.fr();
-      for (uint32_t c = 0; c < A; c++) (void)rng.fr();
-      ZK_TRY(blind_rows(M, pk->adv(), A, usable, bf + 1, tail));
+      if (rng.rng) {
+        ZK_TRY(blind_dev(M, pk->adv(), A, usable, bf + 1, ci * per_adv, bf + 1));
+        rng.rng->skip_blocks(per_adv);
+      } else {
+        std::vector<Fr> tail((size_t)A * (bf + 1));
+        for (auto& v : tail) v = rng.fr();
+        for (uint32_t c = 0; c < A; c++) (void)rng.fr();
+        ZK_TRY(blind_rows(M, pk->adv(), A, usable, bf + 1, tail));
+      }
     }
     Commit cm;
     if (A && !serial && gate_l1) ZK_TRY(commit_begin(M, AMDZK_BASIS_G_LAGRANGE, pk->adv(), A, cm));
@@ -1861,24 +1884,35 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* const* pks, size_t ncirc,
     ZK_TRY(d2d(ctx, pk->la(), pk->ci, (size_t)L * n * 32));
     ZK_TRY(zk_permute_expression_pairs(ctx, pk->la(), pk->ct, pk->lk_ts, pk->ls(), pk->lk_left, pk->lk_flags, pk->d_err, L, (uint32_t)n,
                                        (uint32_t)usable, pk->lk_ts_const, pk->lk_const));
-    ZK_TRY(zk_permute_check(ctx, pk->d_err));
+    // the "input not in table" word comes down behind the permutation and is read once the host has waited for this
+    // phase's commitment anyway (it used to be a host wait of its own in the middle of the phase: 0.1 ms of idle device)
+    *pk->h_err = 0;
+    ZK_HIP(ctx, hipMemcpyAsync(pk->h_err, pk->d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     tick("  lookup: device permute");
     // RNG order per lookup: a' tail, s' tail, blind(a'), blind(s')
-    std::vector<Fr> ta((size_t)L * (bf + 1)), ts((size_t)L * (bf + 1));
-    for (uint32_t l = 0; l < L; l++) {
-      for (uint32_t i = 0; i <= bf; i++) ta[(size_t)l * (bf + 1) + i] = rng.fr();
-      for (uint32_t i = 0; i <= bf; i++) ts[(size_t)l * (bf + 1) + i] = rng.fr();
-      (void)rng.fr();
-      (void)rng.fr();
+    if (rng.rng) {
+      const uint32_t per = 2 * (bf + 1) + 2;
+      ZK_TRY(blind_dev(M, pk->la(), L, usable, bf + 1, base_lk + ci * per_lk, per));
+      ZK_TRY(blind_dev(M, pk->ls(), L, usable, bf + 1, base_lk + ci * per_lk + (bf + 1), per));
+      rng.rng->skip_blocks(per_lk);
+    } else {
+      std::vector<Fr> ta((size_t)L * (bf + 1)), ts((size_t)L * (bf + 1));
+      for (uint32_t l = 0; l < L; l++) {
+        for (uint32_t i = 0; i <= bf; i++) ta[(size_t)l * (bf + 1) + i] = rng.fr();
+        for (uint32_t i = 0; i <= bf; i++) ts[(size_t)l * (bf + 1) + i] = rng.fr();
+        (void)rng.fr();
+        (void)rng.fr();
+      }
+      ZK_TRY(blind_rows(M, pk->la(), L, usable, bf + 1, ta));
+      ZK_TRY(upload_small(ts, ta.size()));
+      ZK_TRY(zk_scatter_rows(ctx, pk->ls(), n, usable, pk0->small + ta.size(), bf + 1, L));
     }
-    ZK_TRY(blind_rows(M, pk->la(), L, usable, bf + 1, ta));
-    ZK_TRY(upload_small(ts, ta.size()));
-    ZK_TRY(zk_scatter_rows(ctx, pk->ls(), n, usable, pk0->small + ta.size(), bf + 1, L));
     Commit cmc;
     if (!serial && gate_l1) ZK_TRY(commit_begin(M, AMDZK_BASIS_G_LAGRANGE, pk->la(), 2 * L, cmc));
     ZK_TRY(transforms_on_B(pk, M, (size_t)A + I, 2 * (size_t)L, cmc.begun));
     if (!cmc.begun) ZK_TRY(commit_begin(M, AMDZK_BASIS_G_LAGRANGE, pk->la(), 2 * L, cmc));
     ZK_TRY(commit_end(cmc));
+    if (*pk->h_err) ZK_FAIL(ctx, AMDZK_E_INVALID, "create_proof: lookup %d input not in table (ConstraintSystemFailure)", *pk->h_err - 1);
     const std::vector<G1Affine>& cm = cmc.pts;
     for (uint32_t l = 0; l < L; l++) {
       std::vector<G1Affine> two = {cm[l], cm[L + l]};
@@ -1904,42 +1938,51 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* const* pks, size_t ncirc,
   // 3. + 4. permutation grand products on M, lookup grand products on C (they depend on beta and gamma only, not on
   // each other). RNG order: the permutation sets' tails and blinds, then the lookups'.
   // (Several instances: every instance's permutation products are committed before the first lookup product.)
-  std::vector<std::vector<Fr>> tail_p_all(NC, std::vector<Fr>((size_t)ns * bf)), tail_l_all(NC, std::vector<Fr>((size_t)L * bf));
-  for (size_t ci = 0; ci < NC; ci++)
-    for (uint32_t s = 0; s < ns; s++) {
-      for (uint32_t i = 0; i < bf; i++) tail_p_all[ci][(size_t)s * bf + i] = rng.fr();
-      (void)rng.fr();
+  std::vector<std::vector<Fr>> tail_p_all(NC), tail_l_all(NC);
+  if (rng.rng) {
+    rng.rng->skip_blocks(NC * (per_pz + per_lz));  // generated on the device, below
+  } else {
+    for (size_t ci = 0; ci < NC; ci++) {
+      tail_p_all[ci].resize((size_t)ns * bf);
+      for (uint32_t s = 0; s < ns; s++) {
+        for (uint32_t i = 0; i < bf; i++) tail_p_all[ci][(size_t)s * bf + i] = rng.fr();
+        (void)rng.fr();
+      }
     }
-  for (size_t ci = 0; ci < NC; ci++)
-    for (uint32_t l = 0; l < L; l++) {
-      for (uint32_t i = 0; i < bf; i++) tail_l_all[ci][(size_t)l * bf + i] = rng.fr();
-      (void)rng.fr();
+    for (size_t ci = 0; ci < NC; ci++) {
+      tail_l_all[ci].resize((size_t)L * bf);
+      for (uint32_t l = 0; l < L; l++) {
+        for (uint32_t i = 0; i < bf; i++) tail_l_all[ci][(size_t)l * bf + i] = rng.fr();
+        (void)rng.fr();
+      }
     }
+  }
   // 5. vanishing: the random polynomial's n draws and its blind (generated above from this position of the stream)
   if (rng.rng) rng.rng->skip_blocks(n);
   else rng.used += n;
   (void)rng.fr();
-  for (size_t ci = 0; ci < NC && L; ci++) {
+  auto lookup_products = [&](size_t ci, bool ordered_behind_m) -> int {
     amdzk_pk* const pk = pks[ci];
     const std::vector<Fr>& tail_l = tail_l_all[ci];
     Commit& cm_zl = cm_zl_all[ci];
-    ZK_TRY(zk_stream_after(C, M));  // beta, gamma and the permuted columns are in place
+    if (!ordered_behind_m) ZK_TRY(zk_stream_after(C, M));  // beta, gamma and the permuted columns are in place
     LN_TRY(C, run_program(C, pk, pk->prog_lfrac, false, pk->d_outs_lfrac, nullptr, "expr_lookup_fractions"));
     LN_TRY(C, zk_batch_invert(C, pk->frac2, pk->scratch2, (size_t)L * n));
     LN_TRY(C, zk_mul_elem(C, pk->zl(), pk->frac2, (size_t)L * n));
     LN_TRY(C, zk_running_product(C, pk->zl(), L, n, n, false, 0, pk->scan_tmp2));
-    ZK_TRY(blind_rows(C, pk->zl(), L, n - bf, bf, tail_l));
+    if (rng.rng) ZK_TRY(blind_dev(C, pk->zl(), L, n - bf, bf, base_lz + ci * per_lz, bf + 1));
+    else ZK_TRY(blind_rows(C, pk->zl(), L, n - bf, bf, tail_l));
     // ... and their commitment, enqueued BEFORE the permutation chain: the lookup chain is the shorter one, so its
     // level-1 kernel runs while M is still in fractions, inversion and scans rather than beside M's own level-1 kernel.
     // (Measured: 18.8-19.3 ms per proof either way — what one lane gains the other loses; kept for the simpler order.)
     if (serial || !gate_l1) ZK_TRY(transforms_on_B(pk, C, (size_t)A + I + 2 * L + ns, L));
     ZK_TRY(commit_begin(C, AMDZK_BASIS_G_LAGRANGE, pk->zl(), L, cm_zl));
     if (!serial && gate_l1) ZK_TRY(transforms_on_B(pk, C, (size_t)A + I + 2 * L + ns, L, true));
-  }
-  for (size_t ci = 0; ci < NC && ns; ci++) {
+    return AMDZK_OK;
+  };
+  auto perm_products = [&](size_t ci) -> int {  // fractions, inversion, running products, blinding: everything in front of the commitment
     amdzk_pk* const pk = pks[ci];
     const std::vector<Fr>& tail_p = tail_p_all[ci];
-    Commit& cm_zp = cm_zp_all[ci];
     ZK_TRY(run_program(ctx, pk, pk->prog_pfrac, false, pk->d_outs_pfrac, nullptr, "expr_perm_fractions"));
     tick("  perm: fractions program");
     ZK_TRY(zk_batch_invert(ctx, pk->frac, pk->scratch, (size_t)ns * n));
@@ -1947,9 +1990,30 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* const* pks, size_t ncirc,
     ZK_TRY(zk_mul_elem(ctx, pk->zp(), pk->frac, (size_t)ns * n));
     ZK_TRY(zk_running_product(ctx, pk->zp(), ns, n, n, true, usable, pk->scan_tmp));
     tick("  perm: running product");
-    ZK_TRY(blind_rows(M, pk->zp(), ns, n - bf, bf, tail_p));
+    if (rng.rng) ZK_TRY(blind_dev(M, pk->zp(), ns, n - bf, bf, base_pz + ci * per_pz, bf + 1));
+    else ZK_TRY(blind_rows(M, pk->zp(), ns, n - bf, bf, tail_p));
+    return AMDZK_OK;
+  };
+  auto perm_commit = [&](size_t ci) -> int {
+    amdzk_pk* const pk = pks[ci];
     if (serial || !gate_l1) ZK_TRY(transforms_on_B(pk, M, (size_t)A + I + 2 * L, ns));
-    ZK_TRY(commit_begin(M, AMDZK_BASIS_G_LAGRANGE, pk->zp(), ns, cm_zp));
+    ZK_TRY(commit_begin(M, AMDZK_BASIS_G_LAGRANGE, pk->zp(), ns, cm_zp_all[ci]));
+    return AMDZK_OK;
+  };
+  if (!serial) {
+    // Lanes (one instance): the HOST enqueues M's chain first — seven launches the transcript waits for — and lane C's
+    // lookup products (a dozen launches and a commitment batch's fourteen) while M's fractions and inversion run: the
+    // device used to sit 0.48 ms behind beta / gamma waiting for M's first kernel (profiles/r03zz_timeline_single_proof.txt).
+    if (L) ZK_TRY(zk_stream_after(C, M));  // C starts behind beta, gamma and the permuted columns — NOT behind M's products below
+    if (ns) ZK_TRY(perm_products(0));
+    if (L) ZK_TRY(lookup_products(0, true));
+    if (ns) ZK_TRY(perm_commit(0));
+  } else {
+    for (size_t ci = 0; ci < NC && L; ci++) ZK_TRY(lookup_products(ci, false));
+    for (size_t ci = 0; ci < NC && ns; ci++) {
+      ZK_TRY(perm_products(ci));
+      ZK_TRY(perm_commit(ci));
+    }
   }
   if (ns && !serial && gate_l1) ZK_TRY(transforms_on_B(pk, M, (size_t)A + I + 2 * L, ns, true));  // lanes: one instance
   for (size_t ci = 0; ci < NC; ci++) {
