@@ -87,6 +87,11 @@ struct amdzk_ctx {
   unsigned order_next = 0;
   // Pipelined commitments (msm.hip zk_msm_dev_xyzz): a batch's column groups alternate between `stream` and this
   // second stream, level-1 kernels chained through msm_evt[0..5]; [6] / [7] order the two streams at entry / exit.
+  // A lone proof's latency against throughput (set by create_proof while a proof runs on lanes, i.e. with a default key):
+  // the commitments' latency-bound stages trade instructions for depth — row / column sums of the bucket reduction as
+  // shuffle trees (6 dependent additions instead of 11, 4.4 x the instructions), small batches in finer tasks. With
+  // several proofs in flight (serial keys) the cheaper forms are the right ones.
+  bool msm_latency_mode = false;
   bool msm_pipeline = false;
   hipStream_t msm_stream = nullptr;
   hipEvent_t msm_evt[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -648,6 +648,213 @@ __global__ __launch_bounds__(64 * ROWCOL_WAVES) void msm_rowcol_kernel(const G1X
   }
 }
 
+// The same sums as shuffle trees (latency mode): one wavefront per output GROUP — workgroup (u, j) of 64 lanes loads the 64
+// buckets of row group g = 64 u' + j (row units) or, transposed, the 64 row groups' buckets of residue r = j (column
+// units), and adds them in six shuffle rounds: depth 6 instead of 8 + 3, at 4.4 x the additions (128 wavefronts x 6 per
+// 64 x 64 block instead of 16 x 11). Same slots, same values as group elements.
+__global__ __launch_bounds__(64) void msm_rowcol_tree_kernel(const G1X29* dense, uint32_t nb, G1X29* rows, G1X29* cols) {
+  const uint32_t col = blockIdx.z, lane = threadIdx.x, j = blockIdx.x;
+  const uint32_t G = nb >> 6, U = (G + 63) >> 6;
+  const bool col_unit = blockIdx.y < U;
+  const uint32_t unit = col_unit ? blockIdx.y : blockIdx.y - U;
+  const G1X29* d = dense + (size_t)col * nb;
+  G1X29 v = G1X29::inf();
+  if (col_unit) {  // residue r = j, row groups 64 unit + lane
+    const uint32_t g = unit * 64 + lane;
+    if (g < G) v = ld_x29(d + 64 * g + j);
+  } else {  // row group g = 64 unit + j, residues r = lane
+    const uint32_t g = unit * 64 + j;
+    if (g < G) v = ld_x29(d + 64 * g + lane);
+  }
+  v = wave_sum29(v);
+  if (lane == 0) {
+    if (col_unit) st_x29(cols + ((size_t)col * U + unit) * 64 + j, v);
+    else if (unit * 64 + j < G) st_x29(rows + (size_t)col * G + unit * 64 + j, v);
+  }
+}
+
+// ------------------------------------------------------------------ quad-lane point additions (latency mode)
+// One XYZZ addition spread over the FOUR lanes of a quad: every lane of the quad holds the same two points (replicated), takes
+// one of the (up to) four independent products of each of the formula's four rounds — its operands picked by its position in
+// the quad — and the results go round the quad with DPP quad_perm moves, so that all four lanes end with the same sum. 4
+// products + selects + broadcasts per lane (~1,300 VALU) instead of 14 products (~3,100): the bucket reduction's chain of ~30
+// dependent additions per commitment batch is what a lone proof waits for (a lone wavefront issues a dependent instruction
+// every ~6 cycles whatever it is), and instruction-level parallelism inside ONE lane bought nothing (profiles/r04c_*).
+// Costs 4 lanes per addition, so only where the chip is empty anyway: amdzk_ctx::msm_latency_mode. Bounds as x29_add
+// (y leaves as the sum of two reduced products, below 4p).
+template <int J> __device__ __forceinline__ Fq29 quad_bcast(const Fq29& v) {
+  Fq29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], J * 0x55, 0xf, 0xf, false);  // quad_perm:[J,J,J,J]
+  return r;
+}
+__device__ __forceinline__ Fq29 quad_sel(uint32_t role, const Fq29& a0, const Fq29& a1, const Fq29& a2, const Fq29& a3) {
+  Fq29 r;
+  const bool hi = (role & 2u) != 0, odd = (role & 1u) != 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const uint32_t lo2 = odd ? a1.l[i] : a0.l[i], hi2 = odd ? a3.l[i] : a2.l[i];
+    r.l[i] = hi ? hi2 : lo2;
+  }
+  return r;
+}
+__device__ __forceinline__ G1X29 x29_dbl_quad(const G1X29& p, uint32_t role) {
+  if (p.is_inf()) return p;
+  const Fq29 u = f29_add(p.y, p.y);                                                   // < 10
+  Fq29 res = f29_mul(quad_sel(role, u, p.x, u, p.x), quad_sel(role, u, p.x, u, p.x));  // u^2 (100 p^2) | x^2 (81)
+  const Fq29 v = quad_bcast<0>(res), xx = quad_bcast<1>(res);
+  const Fq29 m = f29_add(f29_add_lazy(xx, xx), xx);                                   // < 6
+  res = f29_mul(quad_sel(role, u, p.x, m, m), quad_sel(role, v, v, m, m));             // w = u v | s = x v | m^2 (36)
+  const Fq29 w = quad_bcast<0>(res), sv = quad_bcast<1>(res), mm = quad_bcast<2>(res);
+  G1X29 r;
+  r.x = f29_sub5(mm, f29_add(sv, sv));                                                // < 7
+  const Fq29 d = f29_sub8(sv, r.x);                                                   // < 10
+  res = f29_mul(quad_sel(role, m, f29_neg3(w), v, w), quad_sel(role, d, p.y, p.zz, p.zzz));  // m d (60) | (3p - w) y (15) | v zz | w zzz
+  r.y = f29_add(quad_bcast<0>(res), quad_bcast<1>(res));                              // < 4
+  r.zz = quad_bcast<2>(res);
+  r.zzz = quad_bcast<3>(res);
+  return r;
+}
+__device__ __forceinline__ G1X29 x29_add_quad(const G1X29& a, const G1X29& b, uint32_t role) {
+  if (b.is_inf()) return a;  // the four lanes hold the same points: every branch is uniform over the quad
+  if (a.is_inf()) return b;
+  Fq29 res = f29_mul(quad_sel(role, a.x, b.x, a.y, b.y), quad_sel(role, b.zz, a.zz, b.zzz, a.zzz));  // u1 (18 p^2) | u2 | s1 (10) | s2
+  const Fq29 u1 = quad_bcast<0>(res), s1 = quad_bcast<2>(res);
+  const Fq29 p = f29_sub3(quad_bcast<1>(res), u1);                                    // < 5
+  const Fq29 r = f29_sub3(quad_bcast<3>(res), s1);                                    // < 5
+  res = f29_mul(quad_sel(role, p, r, a.zz, a.zzz), quad_sel(role, p, r, b.zz, b.zzz));  // pp (25) | rr | zz1 zz2 | zzz1 zzz2
+  const Fq29 pp = quad_bcast<0>(res), rr = quad_bcast<1>(res), zz12 = quad_bcast<2>(res), zzz12 = quad_bcast<3>(res);
+  if (f29_is_zero_mod_p(pp)) {
+    if (f29_is_zero_mod_p(rr)) return x29_dbl_quad(a, role);
+    return G1X29::inf();
+  }
+  res = f29_mul(quad_sel(role, p, u1, zz12, zz12), pp);                               // ppp (10) | q | zz3
+  const Fq29 ppp = quad_bcast<0>(res), q = quad_bcast<1>(res);
+  G1X29 o;
+  o.zz = quad_bcast<2>(res);
+  const Fq29 sq = f29_add(ppp, f29_add_lazy(q, q));                                   // < 6
+  o.x = f29_sub7(rr, sq);                                                             // < 9
+  const Fq29 t = f29_sub10(q, o.x);                                                   // < 12
+  res = f29_mul(quad_sel(role, r, f29_neg3(s1), zzz12, zzz12), quad_sel(role, t, ppp, ppp, ppp));  // r t (60) | (3p - s1) ppp (6) | zzz3
+  o.y = f29_add(quad_bcast<0>(res), quad_bcast<1>(res));                              // < 4
+  o.zzz = quad_bcast<2>(res);
+  return o;
+}
+
+// A point in LDS as 36 consecutive words; all four lanes of a quad read the same words (a broadcast read).
+__device__ __forceinline__ G1X29 lds_ld_x29(const uint32_t* p) {
+  G1X29 r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    r.x.l[i] = p[i];
+    r.y.l[i] = p[9 + i];
+    r.zz.l[i] = p[18 + i];
+    r.zzz.l[i] = p[27 + i];
+  }
+  return r;
+}
+__device__ __forceinline__ void lds_st_x29(uint32_t* p, const G1X29& v, uint32_t role) {  // each lane of the quad stores one coordinate
+  const Fq29 c = quad_sel(role, v.x, v.y, v.zz, v.zzz);
+#pragma unroll
+  for (int i = 0; i < 9; i++) p[role * 9 + i] = c.l[i];
+}
+
+// A folding level (msm_accum_seg_kernel<false>) with quad additions: quad t owns partial sums [t * T, (t + 1) * T) of the column's
+// list; the four lanes load the same sums, add them together, and lane 0 of the quad stores. Same slots, same values.
+__global__ __launch_bounds__(MSM_THREADS) void msm_accum_fold_quad_kernel(AccArgs a) {
+  const uint32_t col = blockIdx.y;
+  const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, t = gtid >> 2, role = gtid & 3u;
+  const uint32_t* off_in = a.off_in + (size_t)col * (a.nb + 1);
+  const uint32_t* off_out = a.off_out + (size_t)col * (a.nb + 1);
+  const uint32_t total = off_in[a.nb];
+  const uint32_t start = t * a.T;
+  if (start >= total) return;
+  const uint32_t end = min(start + a.T, total);
+  uint32_t lo = 0, hi = a.nb;
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (off_in[mid] <= start) lo = mid; else hi = mid;
+  }
+  uint32_t b = lo, b_end = off_in[b + 1];
+  const G1X29* in = a.in_list + (size_t)col * a.in_cap;
+  G1X29* out = a.out_list + (size_t)col * a.out_cap;
+  G1X29 acc = G1X29::inf();
+  for (uint32_t e = start; e < end; e++) {
+    if (e >= b_end) {
+      if (role == 0) st_x29(out + off_out[b] + (t - off_in[b] / a.T), acc);
+      acc = G1X29::inf();
+      do {
+        b++;
+        b_end = off_in[b + 1];
+      } while (e >= b_end);
+    }
+    acc = x29_add_quad(acc, ld_x29(in + e), role);
+  }
+  if (role == 0) st_x29(out + off_out[b] + (t - off_in[b] / a.T), acc);
+}
+
+// Row / column sums with quad additions: one workgroup of 64 quads per OUTPUT (a row group's 64 residues, or a residue's 64 row
+// groups): the 64 points meet pairwise through LDS in six rounds. grid = (64 outputs, 2 units, columns); nb <= 4096 (G <= 64).
+__global__ __launch_bounds__(256) void msm_rowcol_quad_kernel(const G1X29* dense, uint32_t nb, G1X29* rows, G1X29* cols) {
+  __shared__ uint32_t pts[64 * 36];
+  const uint32_t col = blockIdx.z, j = blockIdx.x, quad = threadIdx.x >> 2, role = threadIdx.x & 3u;
+  const uint32_t G = nb >> 6;
+  const bool col_unit = blockIdx.y == 0;
+  const G1X29* d = dense + (size_t)col * nb;
+  if (!col_unit && j >= G) return;
+  // column unit: residue r = j, this quad's row group g = quad; row unit: row group g = j, this quad's residue r = quad
+  const uint32_t g = col_unit ? quad : j, r_ = col_unit ? j : quad;
+  G1X29 v = g < G ? ld_x29(d + 64 * g + r_) : G1X29::inf();
+  for (uint32_t s = 32; s >= 1; s >>= 1) {
+    if (quad >= s && quad < 2 * s) lds_st_x29(pts + (quad - s) * 36, v, role);
+    __syncthreads();
+    if (quad < s) v = x29_add_quad(v, lds_ld_x29(pts + quad * 36), role);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (col_unit) st_x29(cols + (size_t)col * 64 + j, v);
+    else st_x29(rows + (size_t)col * G + j, v);
+  }
+}
+
+// msm_fold for nb <= 4096 with quad additions: quads [0, 64) hold the row sums T_g, quads [64, 128) the column sums C_r; suffix
+// sums by six shift-and-add rounds through LDS (two buffers per vector), their sum by six halving rounds, then quad 0:
+// out = 64 * sum_g g T_g + sum_g T_g + sum_r r C_r.
+__global__ __launch_bounds__(512) void msm_fold_quad_kernel(const G1X29* rows, const G1X29* cols, uint32_t nb, G1X* out) {
+  __shared__ uint32_t buf[2][2][64 * 36];  // [vector][ping-pong][point]
+  __shared__ uint32_t keep[3 * 36];        // sum_g T_g, sum_g g T_g, sum_r r C_r
+  const uint32_t col = blockIdx.x, quad = threadIdx.x >> 2, role = threadIdx.x & 3u, vec = quad >> 6, l = quad & 63u;
+  const uint32_t G = nb >> 6;
+  G1X29 v = vec == 0 ? (l < G ? ld_x29(rows + (size_t)col * G + l) : G1X29::inf()) : ld_x29(cols + (size_t)col * 64 + l);
+  int cur = 0;
+  lds_st_x29(buf[vec][cur] + l * 36, v, role);
+  __syncthreads();
+  for (uint32_t dd = 1; dd < 64; dd <<= 1) {  // v_l <- v_l + v_{l + dd}: after six rounds the suffix sums S_l
+    if (l + dd < 64) v = x29_add_quad(v, lds_ld_x29(buf[vec][cur] + (l + dd) * 36), role);
+    cur ^= 1;
+    lds_st_x29(buf[vec][cur] + l * 36, v, role);
+    __syncthreads();
+  }
+  if (vec == 0 && l == 0) lds_st_x29(keep, v, role);  // S_0 of the rows = sum_g T_g
+  if (l == 0) v = G1X29::inf();                        // the weighted sum is S_1 + ... + S_63
+  for (uint32_t s = 32; s >= 1; s >>= 1) {
+    __syncthreads();
+    if (l >= s && l < 2 * s) lds_st_x29(buf[vec][cur] + (l - s) * 36, v, role);
+    __syncthreads();
+    if (l < s) v = x29_add_quad(v, lds_ld_x29(buf[vec][cur] + l * 36), role);
+  }
+  if (l == 0) lds_st_x29(keep + (1 + vec) * 36, v, role);
+  __syncthreads();
+  if (quad == 0) {
+    G1X29 acc = lds_ld_x29(keep + 36);
+#pragma unroll 1
+    for (int i = 0; i < 6; i++) acc = x29_dbl_quad(acc, role);
+    acc = x29_add_quad(acc, lds_ld_x29(keep), role);
+    acc = x29_add_quad(acc, lds_ld_x29(keep + 72), role);
+    if (role == 0) st_x(out + col, x29_to_r256(acc));
+  }
+}
+
 __device__ __forceinline__ G1X29 x29_mul_small(const G1X29& p, uint32_t k, int nbits) {
   G1X29 acc = G1X29::inf();
 #pragma unroll 1
@@ -1192,14 +1399,20 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 struct MsmGeom {
   uint32_t c, W, nb, T1, TL, chunk, nblk;
   int nlev;  // accumulation levels in front of the per-bucket final: 2 (level 1 + one fold) or 3
+  bool latency;  // amdzk_ctx::msm_latency_mode at the time of the call
   bool big_digits;  // counting sort with 1024-thread workgroups, up to 256 of them per column
   size_t ecap, cap[4], G;
   size_t o_bh, o_cnt, o_off[4], o_ent, o_list[4], o_dense, o_rows, o_cols, o_ctr, bytes;
 };
 static constexpr int MSM_NLEV = 3;  // at most: level 1 + two folding levels, then the per-bucket final (MsmGeom::nlev of them are used)
 
-static MsmGeom msm_geometry(const amdzk_srs* srs, size_t ncols, size_t len, size_t ncols_for_task_size) {
+static MsmGeom msm_geometry(const amdzk_srs* srs, size_t ncols, size_t len, size_t ncols_for_task_size, bool latency_mode) {
   MsmGeom g;
+  // latency mode applies to batches of a few columns only (the h pieces, the multiopen argument's two, the random polynomial:
+  // the chip is empty behind them); the bucket reduction of a 141-column batch is 2,000 wavefronts and throughput-bound —
+  // spending 4 lanes per addition there made a lone proof 0.4 ms SLOWER (profiles/r04h_*)
+  static const size_t latency_cols = getenv("AMDZK_LATENCY_COLS") && atoi(getenv("AMDZK_LATENCY_COLS")) > 0 ? (size_t)atoi(getenv("AMDZK_LATENCY_COLS")) : 8;
+  g.latency = latency_mode && ncols_for_task_size <= latency_cols;
   g.c = srs->c;
   g.W = srs->W;
   g.nb = 1u << (g.c - 1);
@@ -1286,6 +1499,9 @@ static int msm_group(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const MsmG
   da.ecap = g.ecap;
   da.table_n = (uint32_t)srs->n;
   dim3 dgrid(g.nblk, (unsigned)ncols);
+  // quad-lane point additions in the folds and the bucket reduction: in latency mode (-1), never (0), always (1: tests)
+  static const int tail_quad = getenv("AMDZK_TAIL_QUAD") ? atoi(getenv("AMDZK_TAIL_QUAD")) : -1;
+  const bool quad_on = (tail_quad < 0 ? g.latency : tail_quad != 0) && ncols <= 65535;
   const size_t scan_shmem = (16 + (nb + 1 <= SCAN_LDS_WORDS ? (size_t)nb + 1 : 0)) * sizeof(uint32_t);
   if (scan_shmem > 65536) {
     static bool scan_attr_set = false;  // per process: the attribute belongs to the function, not to the context
@@ -1327,6 +1543,9 @@ static int msm_group(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const MsmG
       else if (l1_lds == 3) ZK_LAUNCH(ctx, "msm_accum_l1", msm_accum_l1_lds_kernel<3>, grid, dim3(L1L_THREADS), 0, a);
       else ZK_LAUNCH(ctx, "msm_accum_l1", msm_accum_seg_kernel<true>, grid, dim3(MSM_THREADS), 0, a);
       if (l1_done) ZK_HIP(ctx, hipEventRecord(l1_done, ctx->stream));
+    } else if (quad_on && !(getenv("AMDZK_FOLD_QUAD") && atoi(getenv("AMDZK_FOLD_QUAD")) == 0)) {
+      const dim3 qgrid((unsigned)((4 * threads + MSM_THREADS - 1) / MSM_THREADS), (unsigned)ncols);
+      ZK_LAUNCH(ctx, "msm_accum_fold", msm_accum_fold_quad_kernel, qgrid, dim3(MSM_THREADS), 0, a);
     } else {
       ZK_LAUNCH(ctx, "msm_accum_fold", msm_accum_seg_kernel<false>, grid, dim3(MSM_THREADS), 0, a);
     }
@@ -1334,8 +1553,16 @@ static int msm_group(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const MsmG
   const unsigned fold_w = (unsigned)((g.G + 63) / 64);  // 1, 2, 4 or 8 (c <= 16): at most 9 wavefronts per workgroup (launch bound 576)
   ZK_LAUNCH(ctx, "msm_accum_final", msm_accum_final_kernel, dim3(nb / 64, (unsigned)ncols), dim3(64), 0, off[g.nlev], nb, list[g.nlev],
             g.cap[g.nlev], dense);
-  ZK_LAUNCH(ctx, "msm_rowcol", msm_rowcol_kernel, dim3((unsigned)(2 * ((g.G + 63) / 64)), (unsigned)ncols), dim3(64 * ROWCOL_WAVES), 0, dense, nb, rows, cols);
-  if (fold_w == 1) ZK_LAUNCH(ctx, "msm_fold", msm_fold_kernel<1>, dim3((unsigned)ncols), dim3(128), 0, rows, cols, nb, outp);
+  static const int tail_tree = getenv("AMDZK_TAIL_TREE") ? atoi(getenv("AMDZK_TAIL_TREE")) : -1;  // -1: in latency mode; 0 / 1: never / always
+  const bool quad = quad_on && fold_w == 1;
+  if (quad)
+    ZK_LAUNCH(ctx, "msm_rowcol", msm_rowcol_quad_kernel, dim3(64, 2, (unsigned)ncols), dim3(256), 0, dense, nb, rows, cols);
+  else if ((tail_tree < 0 ? g.latency : tail_tree != 0) && ncols <= 65535)
+    ZK_LAUNCH(ctx, "msm_rowcol", msm_rowcol_tree_kernel, dim3(64, (unsigned)(2 * ((g.G + 63) / 64)), (unsigned)ncols), dim3(64), 0, dense, nb, rows, cols);
+  else
+    ZK_LAUNCH(ctx, "msm_rowcol", msm_rowcol_kernel, dim3((unsigned)(2 * ((g.G + 63) / 64)), (unsigned)ncols), dim3(64 * ROWCOL_WAVES), 0, dense, nb, rows, cols);
+  if (quad) ZK_LAUNCH(ctx, "msm_fold", msm_fold_quad_kernel, dim3((unsigned)ncols), dim3(512), 0, rows, cols, nb, outp);
+  else if (fold_w == 1) ZK_LAUNCH(ctx, "msm_fold", msm_fold_kernel<1>, dim3((unsigned)ncols), dim3(128), 0, rows, cols, nb, outp);
   else ZK_LAUNCH(ctx, "msm_fold", msm_fold_kernel<8>, dim3((unsigned)ncols), dim3(64 * (fold_w + 1)), 0, rows, cols, nb, outp);
   return AMDZK_OK;
 }
@@ -1361,7 +1588,7 @@ int zk_msm_dev_xyzz(amdzk_ctx* ctx, const amdzk_srs* srs, int basis, const Fr* d
   }
   const size_t gcols = (ncols + ngroups - 1) / ngroups;
   ngroups = (ncols + gcols - 1) / gcols;
-  const MsmGeom g = msm_geometry(srs, gcols, len, ncols);  // task sizes as for the whole batch
+  const MsmGeom g = msm_geometry(srs, gcols, len, ncols, ctx->msm_latency_mode);  // task sizes as for the whole batch
   const size_t o_out = align_up(ngroups * g.bytes, 256);
   char* ws = nullptr;
   ZK_TRY(zk_ws_reserve(ctx, 1, o_out + align_up(ncols * sizeof(G1X), 256), (void**)&ws));

@@ -1727,6 +1727,17 @@ static int create_proof_body(amdzk_ctx* ctx, amdzk_pk* const* pks, size_t ncirc,
     B->msm_pipeline = C->msm_pipeline = ctx->msm_pipeline;
   }
   const bool serial = B == M;
+  // latency mode of the commitments (common.hpp): while this proof runs on lanes; the caller's setting comes back at the end
+  struct LatencyMode {
+    amdzk_ctx* c[3];
+    bool keep[3];
+    LatencyMode(amdzk_ctx* m, amdzk_ctx* b, amdzk_ctx* cc, bool on) : c{m, b, cc} {
+      for (int i = 0; i < 3; i++) keep[i] = c[i]->msm_latency_mode, c[i]->msm_latency_mode = on || keep[i];
+    }
+    ~LatencyMode() {
+      for (int i = 0; i < 3; i++) c[i]->msm_latency_mode = keep[i];
+    }
+  } latency_mode(M, B, C, !serial && !(getenv("AMDZK_LATENCY_MODE") && atoi(getenv("AMDZK_LATENCY_MODE")) == 0));
   auto lane_id = [&](amdzk_ctx* l) { return l == M ? 0 : l == B ? 1 : 2; };
 // a failure on a lane is reported through the caller's ctx
 #define LN_TRY(lane, expr)                                  \

@@ -241,3 +241,20 @@ def test_params_write_read_roundtrip(ctx, pkg, oracle):
     with pytest.raises(pkg.AmdzkError):
         pkg.kzg.ParamsKZG.read(ctx, blob[:100])
     p2.free(); params.free()
+
+
+@pytest.mark.parametrize("env", [{"AMDZK_TAIL_QUAD": "1"}, {"AMDZK_TAIL_QUAD": "0", "AMDZK_TAIL_TREE": "1"}, {"AMDZK_MSM_NLEV": "2"}, {"AMDZK_L1_LDS": "4"}, {"AMDZK_L1_LDS": "9"}])
+def test_alternative_kernels_give_the_same_points(env):
+    """The kernel variants that only run in a proof's latency mode (the bucket reduction with quad-lane point additions, or
+    with shuffle-tree row / column sums) and the measured-and-rejected ones that stay in the tree behind switches (one fold
+    level, level 1 with the accumulator in LDS, level 1 as a persistent grid) must give the oracle's points too: the parity
+    tests above, again, in a child process with the switch forced (the switches are read once per process)."""
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
+                        "golden_vectors or uniform_matches_oracle or edge or batch"], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       timeout=600)
+    assert r.returncode == 0, "%r:\n%s" % (env, r.stdout[-3000:])
+    assert " passed" in r.stdout and "failed" not in r.stdout
