@@ -1399,7 +1399,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 struct MsmGeom {
   uint32_t c, W, nb, T1, TL, chunk, nblk;
   int nlev;  // accumulation levels in front of the per-bucket final: 2 (level 1 + one fold) or 3
-  bool latency;  // amdzk_ctx::msm_latency_mode at the time of the call
+  bool latency;  // latency mode for this batch: amdzk_ctx::msm_latency_mode and a batch of a few columns
   bool big_digits;  // counting sort with 1024-thread workgroups, up to 256 of them per column
   size_t ecap, cap[4], G;
   size_t o_bh, o_cnt, o_off[4], o_ent, o_list[4], o_dense, o_rows, o_cols, o_ctr, bytes;
