@@ -345,8 +345,8 @@ struct ChaChaKey {
 // out[(i / cnt) * out_stride + i % cnt]: cnt = n, strides 0 = n consecutive draws into n consecutive elements (the random
 // polynomial); cnt = blinding rows per column, draw_stride = draws per column in upstream's order (tails, then the unused
 // commitment blinds), out_stride = the column stride = the blinding tails of a batch of columns written in place.
-__global__ __launch_bounds__(256) void chacha20_fr_random_kernel(Fr* out, size_t n, ChaChaKey key, uint64_t counter0, Fr r3, uint32_t cnt,
-                                                                 uint32_t draw_stride, size_t out_stride) {
+__device__ __forceinline__ void chacha20_fr_random_body(Fr* out, size_t n, const ChaChaKey& key, uint64_t counter0, const Fr& r3, uint32_t cnt,
+                                                        uint32_t draw_stride, size_t out_stride) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const size_t grp = i / cnt, r = i % cnt;
@@ -376,6 +376,16 @@ __global__ __launch_bounds__(256) void chacha20_fr_random_kernel(Fr* out, size_t
     d1.l[j] = x[8 + j] + c[8 + j];
   }
   st_fr(out + i, add(mul(Fr::r2(), d0), mul(r3, d1)));
+}
+// Two kernels of one body: the random polynomial of the vanishing argument — ONE launch per proof, the first kernel of every
+// proof, which is what tools/summarize_prof.py and tools/timeline_single_proof.py cut a trace into proofs by — and the
+// blinding tails (several launches per proof).
+__global__ __launch_bounds__(256) void chacha20_fr_random_kernel(Fr* out, size_t n, ChaChaKey key, uint64_t counter0, Fr r3) {
+  chacha20_fr_random_body(out, n, key, counter0, r3, (uint32_t)(n < 0xffffffffu ? n : 0xffffffffu), 0u, (size_t)0);
+}
+__global__ __launch_bounds__(256) void chacha20_blind_rows_kernel(Fr* out, size_t n, ChaChaKey key, uint64_t counter0, Fr r3, uint32_t cnt,
+                                                                  uint32_t draw_stride, size_t out_stride) {
+  chacha20_fr_random_body(out, n, key, counter0, r3, cnt, draw_stride, out_stride);
 }
 
 // ------------------------------------------------------------------------------ batch inversion
@@ -945,8 +955,7 @@ int zk_expr_eval_limbs(amdzk_ctx* ctx, const ExprArgs& a, uint32_t depth, const 
 int zk_chacha20_fr_random(amdzk_ctx* ctx, Fr* d_out, size_t n, const uint32_t key[8], uint64_t counter0, const Fr& r3) {
   ChaChaKey k;
   memcpy(k.k, key, sizeof(k.k));
-  if (n) ZK_LAUNCH(ctx, "chacha20_fr_random", chacha20_fr_random_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_out, n, k, counter0, r3,
-                   (uint32_t)std::min<size_t>(n, 0xffffffffu), 0u, (size_t)0);
+  if (n) ZK_LAUNCH(ctx, "chacha20_fr_random", chacha20_fr_random_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d_out, n, k, counter0, r3);
   return AMDZK_OK;
 }
 
@@ -957,7 +966,7 @@ int zk_chacha20_blind_rows(amdzk_ctx* ctx, Fr* d_cols, size_t col_stride, size_t
   ChaChaKey k;
   memcpy(k.k, key, sizeof(k.k));
   const size_t total = (size_t)cnt * ncols;
-  if (total) ZK_LAUNCH(ctx, "chacha20_blind_rows", chacha20_fr_random_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, d_cols + row0, total, k,
+  if (total) ZK_LAUNCH(ctx, "chacha20_blind_rows", chacha20_blind_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, d_cols + row0, total, k,
                        counter0, r3, cnt, draw_stride, col_stride);
   return AMDZK_OK;
 }
