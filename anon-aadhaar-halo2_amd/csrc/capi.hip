@@ -373,15 +373,31 @@ int amdzk_dev_upload_async(amdzk_ctx* ctx, void* dptr, const void* host, size_t 
     ZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     ZK_HIP(ctx, hipEventCreateWithFlags(&ctx->copy_evt, hipEventDisableTiming));
   }
-  if (bytes) ZK_HIP(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+  if (bytes) {
+    ZK_HIP(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    // the completion marker travels with the copy (not with the fence): by the time a pipelined caller fences, the copy
+    // queue has long gone idle, and a marker sent to an idle queue is only seen when the hardware scheduler next maps it
+    ZK_HIP(ctx, hipEventRecord(ctx->copy_evt, ctx->copy_stream));
+    ctx->copy_pending = true;
+  }
   return AMDZK_OK;
 }
+// Order the context's stream behind its uploads. A caller that overlaps the next witness's upload with the current proof
+// (feeder.py) fences a copy that finished long ago: the host sees that with one event query and the proof's stream gets NO
+// cross-queue dependency. (With one in front of every proof, eight proofs that run in step all stalled on the hardware
+// scheduler at the same moment: 5-10 % of the rate in some timed regions, profiles/r04y_streamed_regions_in_step.txt.)
+// Only a copy still in flight is waited for, on the device.
 int amdzk_upload_fence(amdzk_ctx* ctx) {
   ZK_ENTER(ctx);
   if (!ctx) return AMDZK_E_INVALID;
-  if (!ctx->copy_stream) return AMDZK_OK;  // nothing was ever uploaded asynchronously
-  ZK_HIP(ctx, hipEventRecord(ctx->copy_evt, ctx->copy_stream));
-  ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->copy_evt, 0));
+  if (!ctx->copy_stream || !ctx->copy_pending) return AMDZK_OK;  // nothing uploaded asynchronously since the last fence
+  hipError_t q = hipEventQuery(ctx->copy_evt);
+  if (q == hipErrorNotReady) {
+    ZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->copy_evt, 0));
+  } else {
+    ZK_HIP(ctx, q);
+  }
+  ctx->copy_pending = false;
   return AMDZK_OK;
 }
 

@@ -42,6 +42,7 @@ struct amdzk_ctx {
   // second stream for amdzk_dev_upload_async (created on first use) and the event its fence waits on
   hipStream_t copy_stream = nullptr;
   hipEvent_t copy_evt = nullptr;
+  bool copy_pending = false;  // an upload has been issued since the last amdzk_upload_fence
   std::string err;
   int num_cu = 256;
 

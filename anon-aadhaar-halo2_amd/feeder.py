@@ -7,6 +7,8 @@ proving context owns two device buffers; while proof i runs out of one, the witn
 pinned host memory into the other on the context's copy stream (amdzk_dev_upload_async), and the create_proof
 that reads it is ordered behind the copy on the device (amdzk_upload_fence) — no host wait, no pageable staging.
 """
+import os
+
 import numpy as np
 
 
@@ -38,13 +40,19 @@ class WitnessStream:
         self.cur = 0
         self.pending = False
         self.pending_src = None
+        self.chunk = int(float(os.environ.get("AMDZK_UPLOAD_CHUNK_MIB", "0")) * (1 << 20))
 
     def prefetch(self, pinned):
         """Start copying `pinned` (PinnedWitness) into the idle buffer. The previous reader of that buffer — the
         proof before the current one — has returned, so the buffer is free."""
         assert not self.pending, "one prefetch per acquire"
         assert pinned.nbytes <= self.nbytes
-        self.ctx.upload_async(self.bufs[self.cur ^ 1], pinned.ptr, pinned.nbytes)
+        dst = self.bufs[self.cur ^ 1]
+        if self.chunk and self.chunk < pinned.nbytes:
+            for off in range(0, pinned.nbytes, self.chunk):
+                self.ctx.upload_async_at(dst, off, pinned.ptr + off, min(self.chunk, pinned.nbytes - off))
+        else:
+            self.ctx.upload_async(dst, pinned.ptr, pinned.nbytes)
         self.pending = True
         self.pending_src = pinned
 

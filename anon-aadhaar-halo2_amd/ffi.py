@@ -242,6 +242,11 @@ class Context:
         """Start a host->device copy on the ctx's copy stream (host_ptr: address of pinned memory)."""
         self._chk(self.L.amdzk_dev_upload_async(self.h, dbuf.ptr, C.c_void_p(host_ptr), nbytes))
 
+    def upload_async_at(self, dbuf, offset, host_ptr, nbytes):
+        """upload_async into dbuf + offset (a witness sent as several copies)."""
+        assert offset + nbytes <= dbuf.nbytes
+        self._chk(self.L.amdzk_dev_upload_async(self.h, C.c_void_p(dbuf.ptr.value + offset), C.c_void_p(host_ptr), nbytes))
+
     def upload_fence(self):
         self._chk(self.L.amdzk_upload_fence(self.h))
 

@@ -72,6 +72,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-serial-latency", action="store_true",
                     help="skip the single-proof latency of a key made with AMDZK_KEYGEN_SERIAL (one stream per proof, as in rounds 1-2; "
                          "one more keygen and a few proofs; tools/profile_gpu.sh)")
+    ap.add_argument("--stagger-ms", type=float, default=float(os.environ.get("AMDZK_BENCH_STAGGER_MS", "0")),
+                    help="worker w starts its share of a timed region w x this many ms late (inside the timed region): the proofs in flight then sit "
+                         "in different phases instead of in step")
     ap.add_argument("--regions", type=int, default=5, help="how many times the timed region (--steps proofs per GPU) runs; the median is reported")
     ap.add_argument("--host-cores", type=int, default=0,
                     help="confine this rank to the first N cores of its affinity mask (sched_setaffinity before any GPU call); 0 = leave it alone")
@@ -191,6 +194,11 @@ class GpuProver:
         pkg = self.pkg = ge.load_package()
         check_library_stamp(pkg)
         self.plonk = pkg.plonk
+        self.trace = None
+        if os.environ.get("AMDZK_BENCH_TRACE"):
+            # diagnosis only: (context index, start, end) of every create_proof, dumped as JSON at close()
+            self.trace = [(-3, time.time(), time.perf_counter())]  # wall-clock anchor for the perf_counter stamps
+            self.plonk = _TracedPlonk(pkg.plonk, self.trace)
         wl = pkg.workloads
         self.P = P
         self.ctxs = [pkg.Context(local_rank) for _ in range(P)]
@@ -289,6 +297,10 @@ class GpuProver:
                                             then=None if then is None else self.pinned[then])
 
     def close(self):
+        if self.trace is not None:
+            idx = {id(cx): i for i, cx in enumerate(self.ctxs)}
+            with open(os.environ["AMDZK_BENCH_TRACE"], "w") as f:
+                json.dump([[idx.get(c, c if c < 0 else -9), round(a, 6), round(b, 6)] for c, a, b in self.trace], f)
         if self.streams:
             for s in self.streams:
                 s.free()
@@ -300,6 +312,22 @@ class GpuProver:
         self.params.free()
         for cx in self.ctxs:
             cx.close()
+
+
+class _TracedPlonk:
+    """AMDZK_BENCH_TRACE: the plonk module with create_proof timed on the host clock (everything else passes through)."""
+
+    def __init__(self, plonk, log):
+        self._plonk, self._log = plonk, log
+
+    def __getattr__(self, name):
+        return getattr(self._plonk, name)
+
+    def create_proof(self, ctx, *a, **kw):
+        t0 = time.perf_counter()
+        out = self._plonk.create_proof(ctx, *a, **kw)
+        self._log.append((id(ctx), t0, time.perf_counter()))
+        return out
 
 
 def check_library_stamp(pkg):
@@ -506,12 +534,18 @@ def run_rank(args):
             barrier()
             c0 = time.process_time()
             t0 = time.perf_counter()
+            if getattr(prover, "trace", None) is not None:
+                prover.trace.append((-1 if streamed else -2, t0, t0))  # region start marker
+            def lag(cx):
+                if args.stagger_ms > 0:
+                    time.sleep(cx * args.stagger_ms * 1e-3)
+
             if streamed:
                 nxt = reg + 1 < R_
-                pr = run_pool(P, list(range(P)), lambda _, cx: prover.prove_stream(
-                    cx, items[cx], then=per_worker[cx][0][0] if (nxt and per_worker[cx]) else None))
+                pr = run_pool(P, list(range(P)), lambda _, cx: (lag(cx), prover.prove_stream(
+                    cx, items[cx], then=per_worker[cx][0][0] if (nxt and per_worker[cx]) else None))[1])
             else:
-                pr = run_pool(P, list(range(P)), lambda _, cx: [prover.prove(cx, wi, seed) for wi, seed in items[cx]])
+                pr = run_pool(P, list(range(P)), lambda _, cx: (lag(cx), [prover.prove(cx, wi, seed) for wi, seed in items[cx]])[1])
             barrier()
             regs.append((max_over_ranks(time.perf_counter() - t0), time.process_time() - c0))
             if reg == 0:
@@ -764,14 +798,16 @@ def pmc_counters(kernel):
                     stale = stale or os.path.basename(path)
                     continue
                 mad_share = None
-                pos = f.tell()
-                second = f.readline()
-                if second.startswith("# msm_accum_l1_mad_share="):
-                    mad_share = float(second.split("=", 1)[1].split()[0])
-                else:
-                    f.seek(pos)
-                for row in csv.DictReader(f):
-                    if row["kernel"] == names.get(kernel, kernel):
+                body = []
+                for line in f:  # further '#' lines are notes; only the mad share is read
+                    if line.startswith("# msm_accum_l1_mad_share="):
+                        mad_share = float(line.split("=", 1)[1].split()[0])
+                    elif not line.startswith("#"):
+                        body.append(line)
+                if not body or "SQ_INSTS_VALU_per_launch" not in body[0]:
+                    continue  # another command's summary (tools/summarize_k22.py writes *_k22_kernel_summary.csv)
+                for row in csv.DictReader(body):
+                    if row.get("kernel") == names.get(kernel, kernel):
                         out = {"source": "profiles/%s (rocprofv3 --pmc, raw, per launch; kernel sources %s)" % (os.path.basename(path), want)}
                         if row.get("FETCH_SIZE_KiB_per_launch_raw") and row.get("WRITE_SIZE_KiB_per_launch_raw"):
                             out["traffic"] = round((float(row["FETCH_SIZE_KiB_per_launch_raw"]) + float(row["WRITE_SIZE_KiB_per_launch_raw"])) * 1024)

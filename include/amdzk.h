@@ -99,8 +99,9 @@ int amdzk_dev_memset(amdzk_ctx* ctx, void* dptr, int byte, size_t bytes);
  * /root/reference/src/lib.rs:328-397, does): synthesize into pinned host memory (amdzk_host_alloc), start the
  * upload of the NEXT proof's witness with amdzk_dev_upload_async — it runs on a second HIP stream of the ctx,
  * beside the kernels of the proof in progress — and call amdzk_upload_fence before the create_proof that reads
- * it: work submitted to the ctx after the fence waits (on the device, not on the host) for every upload issued
- * before it. The source of an asynchronous upload must stay untouched until a fence + amdzk_sync, or the
+ * it: work submitted to the ctx after the fence runs after every upload issued before it. The fence never blocks
+ * the host: uploads that have already finished (the pipelined case) cost one event query and put no dependency on
+ * the ctx's stream; one still in flight is waited for on the device. The source of an asynchronous upload must stay untouched until a fence + amdzk_sync, or the
  * create_proof that follows the fence, has returned. */
 int amdzk_host_alloc(amdzk_ctx* ctx, size_t bytes, void** hptr);
 int amdzk_host_free(amdzk_ctx* ctx, void* hptr);
