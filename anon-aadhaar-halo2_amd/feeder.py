@@ -8,6 +8,9 @@ pinned host memory into the other on the context's copy stream (amdzk_dev_upload
 that reads it is ordered behind the copy on the device (amdzk_upload_fence) — no host wait, no pageable staging.
 """
 import os
+import queue
+import threading
+import time
 
 import numpy as np
 
@@ -31,6 +34,54 @@ class PinnedWitness:
         self.buf.free()
 
 
+class PacedUploader:
+    """One thread per process that issues the witness uploads of ALL contexts in arrival order, a few MiB at a time and no
+    faster than `rate` bytes/s in total. Uploads have a whole proof's time to arrive; sent at full speed they share the PCIe
+    link with the command packets and kernel arguments the GPU fetches from host memory, and when several proofs run in step
+    all their uploads fall on the same instant (profiles/r04y_streamed_regions_in_step.txt). Enabled by
+    AMDZK_UPLOAD_RATE_GBS > 0; each job's `issued` event is set when its last copy has been handed to the runtime."""
+
+    CHUNK = 4 << 20
+    _inst = None
+    _lock = threading.Lock()
+
+    @classmethod
+    def get(cls, rate):
+        with cls._lock:
+            if cls._inst is None:
+                cls._inst = cls(rate)
+            return cls._inst
+
+    def __init__(self, rate):
+        self.rate = float(rate)
+        self.q = queue.Queue()
+        self.t = threading.Thread(target=self._run, name="amdzk-uploader", daemon=True)
+        self.t.start()
+
+    def submit(self, ctx, dst, pinned):
+        job = (ctx, dst, pinned.ptr, pinned.nbytes, threading.Event(), [])
+        self.q.put(job)
+        return job
+
+    def _run(self):
+        due = time.perf_counter()
+        while True:
+            ctx, dst, ptr, nbytes, issued, err = self.q.get()
+            try:
+                for off in range(0, nbytes, self.CHUNK):
+                    n = min(self.CHUNK, nbytes - off)
+                    now = time.perf_counter()
+                    if due > now:
+                        time.sleep(due - now)
+                    else:
+                        due = now
+                    ctx.upload_async_at(dst, off, ptr + off, n)
+                    due += n / self.rate
+            except BaseException as e:  # noqa: BLE001 - handed to the thread that acquires the buffer
+                err.append(e)
+            issued.set()
+
+
 class WitnessStream:
     """Double-buffered device staging for ONE proving context (one proof at a time per context)."""
 
@@ -41,6 +92,9 @@ class WitnessStream:
         self.pending = False
         self.pending_src = None
         self.chunk = int(float(os.environ.get("AMDZK_UPLOAD_CHUNK_MIB", "0")) * (1 << 20))
+        rate = float(os.environ.get("AMDZK_UPLOAD_RATE_GBS", "0")) * 1e9
+        self.uploader = PacedUploader.get(rate) if rate > 0 else None
+        self.job = None
 
     def prefetch(self, pinned):
         """Start copying `pinned` (PinnedWitness) into the idle buffer. The previous reader of that buffer — the
@@ -48,7 +102,9 @@ class WitnessStream:
         assert not self.pending, "one prefetch per acquire"
         assert pinned.nbytes <= self.nbytes
         dst = self.bufs[self.cur ^ 1]
-        if self.chunk and self.chunk < pinned.nbytes:
+        if self.uploader is not None:
+            self.job = self.uploader.submit(self.ctx, dst, pinned)
+        elif self.chunk and self.chunk < pinned.nbytes:
             for off in range(0, pinned.nbytes, self.chunk):
                 self.ctx.upload_async_at(dst, off, pinned.ptr + off, min(self.chunk, pinned.nbytes - off))
         else:
@@ -60,6 +116,11 @@ class WitnessStream:
         """The buffer holding the most recently prefetched witness; everything submitted to the ctx from now on
         runs after its copy."""
         assert self.pending, "acquire without prefetch"
+        if self.job is not None:
+            self.job[4].wait()
+            err, self.job = self.job[5], None
+            if err:
+                raise err[0]
         self.ctx.upload_fence()
         self.cur ^= 1
         self.pending = False
