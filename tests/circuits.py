@@ -158,3 +158,187 @@ def lookup_circuit(plonk, k=5, seed=1, tables="range_first"):
     c.copy(a, r1, a, r2)
     check_satisfied(c)
     return c
+
+
+def random_circuit(plonk, k=6, seed=0):
+    """A random constraint system with a satisfying witness — the shapes no hand-written fixture has: 0-2 instance columns,
+    gates over queries at rotations -3..3 of advice, fixed AND instance columns (degree 2-6, so 1-5 quotient pieces), several
+    polynomials per gate, 0-3 lookups of 1-3 columns with plain, scaled and summed table expressions and with or without a
+    selector on the inputs, a permutation over a random subset of columns of all three kinds (or none at all), constants.
+
+    Construction: every gate polynomial is  s * (out - f(...))  with `out` an advice column of its own at rotation 0 and f a
+    random expression over the other columns, enabled on rows whose rotated queries stay inside the usable rows; free cells
+    get random values, copy constraints are applied to them (union of cells = one value), then the `out` cells are computed.
+    Lookup inputs live in advice columns of their own (readable by gates, outside the permutation)."""
+    rnd = np.random.RandomState(1000 + seed)
+    ri = lambda lo, hi: int(rnd.randint(lo, hi + 1))  # inclusive
+    cs = plonk.ConstraintSystem()
+    n_free, n_fixed, n_inst = ri(1, 4), ri(1, 3), ri(0, 2)
+    free = [cs.advice_column() for _ in range(n_free)]
+    fixed = [cs.fixed_column() for _ in range(n_fixed)]
+    inst = [cs.instance_column() for _ in range(n_inst)]
+    n_lk = ri(0, 3)
+    lookups = []  # (selector or None, [advice columns], [table fixed columns], table flavour)
+    for _ in range(n_lk):
+        w = ri(1, 3)
+        lookups.append((cs.selector() if rnd.rand() < 0.7 else None, [cs.advice_column() for _ in range(w)],
+                        [cs.fixed_column() for _ in range(w)], ri(0, 2)))
+    readable = free + [col for lk in lookups for col in lk[1]]
+
+    def rand_query(m):
+        kind = rnd.rand()
+        rot = ri(-3, 3) if rnd.rand() < 0.6 else 0
+        if kind < 0.6 or (kind >= 0.85 and not inst):
+            return m.query_advice(readable[ri(0, len(readable) - 1)], rot)
+        if kind < 0.85:
+            return m.query_fixed(fixed[ri(0, n_fixed - 1)], rot)
+        return m.query_instance(inst[ri(0, n_inst - 1)], rot)
+
+    def rand_expr(m, deg):
+        """an expression of degree <= deg (and usually = deg)"""
+        if deg <= 1:
+            r_ = rnd.rand()
+            if r_ < 0.15:
+                return plonk.Expression.constant(ri(0, 1 << 20))
+            q = rand_query(m)
+            if r_ < 0.3:
+                return q * ri(2, 1 << 16)
+            if r_ < 0.4:
+                return -q
+            return q
+        r_ = rnd.rand()
+        if r_ < 0.55:
+            d1 = ri(1, deg - 1)
+            return rand_expr(m, d1) * rand_expr(m, deg - d1)
+        if r_ < 0.8:
+            return rand_expr(m, deg) + rand_expr(m, ri(1, deg))
+        if r_ < 0.9:
+            return rand_expr(m, deg) - rand_expr(m, ri(0, deg))
+        return rand_expr(m, deg) * ri(2, 99)
+
+    gates = []  # (selector, out column, f as tuple) per polynomial
+    n_gates = ri(1, 3)
+    for _ in range(n_gates):
+        sel = cs.selector()
+        polys = []
+        for _ in range(ri(1, 2)):
+            polys.append((cs.advice_column(), ri(1, 5)))
+
+        def gate(m, sel=sel, polys=polys):
+            out = []
+            s = m.query_selector(sel)
+            for col, deg in polys:
+                f = rand_expr(m, deg)
+                gates.append((sel, col, f.to_tuple()))
+                out.append(s * (m.query_advice(col, 0) - f))
+            return out
+
+        cs.create_gate(gate)
+    for sel, cols, tcols, flavour in lookups:
+        def lk(m, sel=sel, cols=cols, tcols=tcols, flavour=flavour):
+            pairs = []
+            for a_, t_ in zip(cols, tcols):
+                inp = m.query_advice(a_, 0)
+                if sel is not None:
+                    inp = m.query_selector(sel) * inp
+                t = m.query_fixed(t_, 0)
+                tab = t if flavour == 0 else (t * 3 - t * 2 if flavour == 1 else t + plonk.Expression.constant(0))
+                pairs.append((inp, tab))
+            if flavour == 2 and len(cols) >= 2:  # one more pair: the same linear combination of inputs and of table columns
+                inp = m.query_advice(cols[0], 0) + m.query_advice(cols[1], 0) * 5
+                if sel is not None:
+                    inp = m.query_selector(sel) * inp
+                pairs.append((inp, m.query_fixed(tcols[0], 0) + m.query_fixed(tcols[1], 0) * 5))
+            return pairs
+        cs.lookup(lk)
+    # permutation: a random subset of the free advice, plain fixed and instance columns (possibly empty)
+    eq_cols = [col for col in free + fixed + inst if rnd.rand() < 0.6]
+    for col in eq_cols:
+        cs.enable_equality(col)
+    c = Circuit(cs, k)
+    c.assembly = plonk.Assembly(c.n, len(cs.permutation_columns))
+    n, u = c.n, c.usable
+    # free cells
+    for col in free:
+        for row in range(u):
+            c.advice[col.index][row] = ri(0, 1 << 30) if rnd.rand() < 0.8 else int(rnd.randint(0, 1 << 62)) * int(rnd.randint(1, 1 << 62)) % R
+    for col in fixed:
+        for row in range(u):
+            c.fixed[col.index][row] = ri(0, 1 << 16) if rnd.rand() < 0.7 else 0
+    for j, col in enumerate(inst):
+        c.instances[col.index] = [ri(0, 1 << 40) for _ in range(ri(0, min(u, 9)))]
+    # tables and lookup inputs
+    for sel, cols, tcols, flavour in lookups:
+        rows_t = ri(2, min(u, 24))
+        table = [tuple(0 for _ in cols)] + [tuple(ri(0, 40) for _ in cols) for _ in range(rows_t - 1)]
+        for row in range(u):
+            tup = table[row] if row < rows_t else table[ri(0, rows_t - 1)]
+            for t_, v in zip(tcols, tup):
+                c.fixed[t_.index][row] = v
+        for row in range(u):
+            on = sel is None or rnd.rand() < 0.6
+            if sel is not None:
+                c.fixed[sel.index][row] = 1 if on else 0
+            tup = table[ri(0, rows_t - 1)] if on else tuple(ri(0, 1 << 20) for _ in cols)  # a disabled row may hold anything
+            for a_, v in zip(cols, tup):
+                c.advice[a_.index][row] = v
+    # copy constraints between free cells (advice / fixed / instance cells inside the assigned instance vector): one value per class
+    def setv(col, row, v):
+        if col.kind == 0:
+            c.advice[col.index][row] = v
+        elif col.kind == 1:
+            c.fixed[col.index][row] = v
+        else:
+            c.instances[col.index][row] = v
+    def rows_of(col):
+        return len(c.instances[col.index]) if col.kind == 2 else u
+    cells = [col for col in eq_cols if rows_of(col) > 0]
+    if cells:
+        parent = {}
+        def find(x):
+            while parent.setdefault(x, x) != x:
+                parent[x] = parent[parent[x]]
+                x = parent[x]
+            return x
+        for _ in range(ri(0, 3 * len(cells) + 2)):
+            c1, c2 = cells[ri(0, len(cells) - 1)], cells[ri(0, len(cells) - 1)]
+            r1, r2 = ri(0, rows_of(c1) - 1), ri(0, rows_of(c2) - 1)
+            if (c1, r1) == (c2, r2):
+                continue
+            c.copy(c1, r1, c2, r2)
+            parent[find((c1, r1))] = find((c2, r2))
+        for (col, row) in list(parent):
+            root = find((col, row))
+            setv(col, row, c.value(root[0], root[1]))
+    # the gates' out cells, on rows whose rotated queries stay in [0, u)
+    full_inst = lambda: [list(v) + [0] * (n - len(v)) for v in c.instances]
+    iv = full_inst()
+
+    def ev(e, row):
+        op = e[0]
+        if op == "const":
+            return e[1]
+        if op == "fixed":
+            return c.fixed[e[1]][(row + e[2]) % n]
+        if op == "advice":
+            return c.advice[e[1]][(row + e[2]) % n]
+        if op == "instance":
+            return iv[e[1]][(row + e[2]) % n]
+        if op == "neg":
+            return (-ev(e[1], row)) % R
+        if op == "sum":
+            return (ev(e[1], row) + ev(e[2], row)) % R
+        if op == "product":
+            return ev(e[1], row) * ev(e[2], row) % R
+        return ev(e[1], row) * e[2] % R
+
+    sel_rows = {}
+    for sel, col, f in gates:
+        if sel.index not in sel_rows:
+            sel_rows[sel.index] = [row for row in range(3, u - 3) if rnd.rand() < 0.7]
+            for row in sel_rows[sel.index]:
+                c.fixed[sel.index][row] = 1
+        for row in range(u):
+            c.advice[col.index][row] = ev(f, row) if row in set(sel_rows[sel.index]) else ri(0, 1 << 30)
+    check_satisfied(c)
+    return c
