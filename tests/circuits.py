@@ -258,16 +258,12 @@ def random_circuit(plonk, k=6, seed=0):
     c = Circuit(cs, k)
     c.assembly = plonk.Assembly(c.n, len(cs.permutation_columns))
     n, u = c.n, c.usable
-    # free cells
-    for col in free:
-        for row in range(u):
-            c.advice[col.index][row] = ri(0, 1 << 30) if rnd.rand() < 0.8 else int(rnd.randint(0, 1 << 62)) * int(rnd.randint(1, 1 << 62)) % R
+    # ---- layout (the proving key's part): fixed columns, tables, selector rows, instance lengths, copy constraints
     for col in fixed:
         for row in range(u):
             c.fixed[col.index][row] = ri(0, 1 << 16) if rnd.rand() < 0.7 else 0
-    for j, col in enumerate(inst):
-        c.instances[col.index] = [ri(0, 1 << 40) for _ in range(ri(0, min(u, 9)))]
-    # tables and lookup inputs
+    inst_len = [ri(0, min(u, 9)) for _ in inst]
+    tables = []
     for sel, cols, tcols, flavour in lookups:
         rows_t = ri(2, min(u, 24))
         table = [tuple(0 for _ in cols)] + [tuple(ri(0, 40) for _ in cols) for _ in range(rows_t - 1)]
@@ -275,31 +271,29 @@ def random_circuit(plonk, k=6, seed=0):
             tup = table[row] if row < rows_t else table[ri(0, rows_t - 1)]
             for t_, v in zip(tcols, tup):
                 c.fixed[t_.index][row] = v
-        for row in range(u):
-            on = sel is None or rnd.rand() < 0.6
-            if sel is not None:
-                c.fixed[sel.index][row] = 1 if on else 0
-            tup = table[ri(0, rows_t - 1)] if on else tuple(ri(0, 1 << 20) for _ in cols)  # a disabled row may hold anything
-            for a_, v in zip(cols, tup):
-                c.advice[a_.index][row] = v
-    # copy constraints between free cells (advice / fixed / instance cells inside the assigned instance vector): one value per class
-    def setv(col, row, v):
-        if col.kind == 0:
-            c.advice[col.index][row] = v
-        elif col.kind == 1:
-            c.fixed[col.index][row] = v
-        else:
-            c.instances[col.index][row] = v
+        on_rows = [sel is None or rnd.rand() < 0.6 for _ in range(u)]
+        if sel is not None:
+            for row in range(u):
+                c.fixed[sel.index][row] = 1 if on_rows[row] else 0
+        tables.append((table, on_rows))
+    sel_rows = {}
+    for sel, col, f in gates:
+        if sel.index not in sel_rows:
+            sel_rows[sel.index] = set(row for row in range(3, u - 3) if rnd.rand() < 0.7)
+            for row in sel_rows[sel.index]:
+                c.fixed[sel.index][row] = 1
+
     def rows_of(col):
-        return len(c.instances[col.index]) if col.kind == 2 else u
+        return inst_len[inst.index(col)] if col.kind == 2 else u
     cells = [col for col in eq_cols if rows_of(col) > 0]
+    parent = {}
+
+    def find(x):
+        while parent.setdefault(x, x) != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
     if cells:
-        parent = {}
-        def find(x):
-            while parent.setdefault(x, x) != x:
-                parent[x] = parent[parent[x]]
-                x = parent[x]
-            return x
         for _ in range(ri(0, 3 * len(cells) + 2)):
             c1, c2 = cells[ri(0, len(cells) - 1)], cells[ri(0, len(cells) - 1)]
             r1, r2 = ri(0, rows_of(c1) - 1), ri(0, rows_of(c2) - 1)
@@ -307,38 +301,62 @@ def random_circuit(plonk, k=6, seed=0):
                 continue
             c.copy(c1, r1, c2, r2)
             parent[find((c1, r1))] = find((c2, r2))
-        for (col, row) in list(parent):
-            root = find((col, row))
-            setv(col, row, c.value(root[0], root[1]))
-    # the gates' out cells, on rows whose rotated queries stay in [0, u)
-    full_inst = lambda: [list(v) + [0] * (n - len(v)) for v in c.instances]
-    iv = full_inst()
+    classes = {}
+    for cell in list(parent):
+        classes.setdefault(find(cell), []).append(cell)
+    for members in classes.values():  # fixed cells of one class hold one value (part of the key)
+        fx = [m for m in members if m[0].kind == 1]
+        for col, row in fx[1:]:
+            c.fixed[col.index][row] = c.fixed[fx[0][0].index][fx[0][1]]
 
-    def ev(e, row):
+    def ev(e, row, advice, iv):
         op = e[0]
         if op == "const":
             return e[1]
         if op == "fixed":
             return c.fixed[e[1]][(row + e[2]) % n]
         if op == "advice":
-            return c.advice[e[1]][(row + e[2]) % n]
+            return advice[e[1]][(row + e[2]) % n]
         if op == "instance":
             return iv[e[1]][(row + e[2]) % n]
         if op == "neg":
-            return (-ev(e[1], row)) % R
+            return (-ev(e[1], row, advice, iv)) % R
         if op == "sum":
-            return (ev(e[1], row) + ev(e[2], row)) % R
+            return (ev(e[1], row, advice, iv) + ev(e[2], row, advice, iv)) % R
         if op == "product":
-            return ev(e[1], row) * ev(e[2], row) % R
-        return ev(e[1], row) * e[2] % R
+            return ev(e[1], row, advice, iv) * ev(e[2], row, advice, iv) % R
+        return ev(e[1], row, advice, iv) * e[2] % R
 
-    sel_rows = {}
-    for sel, col, f in gates:
-        if sel.index not in sel_rows:
-            sel_rows[sel.index] = [row for row in range(3, u - 3) if rnd.rand() < 0.7]
-            for row in sel_rows[sel.index]:
-                c.fixed[sel.index][row] = 1
-        for row in range(u):
-            c.advice[col.index][row] = ev(f, row) if row in set(sel_rows[sel.index]) else ri(0, 1 << 30)
+    # ---- one witness of that layout
+    def assign(wseed):
+        wr = np.random.RandomState(77000 + 131 * seed + wseed)
+        wi = lambda lo, hi: int(wr.randint(lo, hi + 1))
+        advice = [[0] * n for _ in range(cs.num_advice)]
+        instances = [[wi(0, 1 << 40) for _ in range(ln)] for ln in inst_len]
+        for col in free:
+            for row in range(u):
+                advice[col.index][row] = wi(0, 1 << 30) if wr.rand() < 0.8 else int(wr.randint(0, 1 << 62)) * int(wr.randint(1, 1 << 62)) % R
+        for (sel, cols, tcols, flavour), (table, on_rows) in zip(lookups, tables):
+            for row in range(u):
+                tup = table[wi(0, len(table) - 1)] if on_rows[row] else tuple(wi(0, 1 << 20) for _ in cols)  # a disabled row may hold anything
+                for a_, v in zip(cols, tup):
+                    advice[a_.index][row] = v
+        for members in classes.values():  # one value per class of copied cells: the fixed cell's if it has one
+            fx = [m for m in members if m[0].kind == 1]
+            col0, row0 = fx[0] if fx else members[0]
+            v = c.fixed[col0.index][row0] if col0.kind == 1 else (advice[col0.index][row0] if col0.kind == 0 else instances[col0.index][row0])
+            for col, row in members:
+                if col.kind == 0:
+                    advice[col.index][row] = v
+                elif col.kind == 2:
+                    instances[col.index][row] = v
+        iv = [list(v) + [0] * (n - len(v)) for v in instances]
+        for sel, col, f in gates:  # the gates' out cells, on rows whose rotated queries stay in [0, u)
+            for row in range(u):
+                advice[col.index][row] = ev(f, row, advice, iv) if row in sel_rows[sel.index] else wi(0, 1 << 30)
+        return advice, instances
+
+    c.advice, c.instances = assign(0)
+    c._witness_fn = assign
     check_satisfied(c)
     return c

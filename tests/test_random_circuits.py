@@ -109,3 +109,60 @@ def test_device_proof_bytes_equal_oracle_on_random_circuits(ctx, pkg, plonk, ora
     if seed % 4 == 1:
         assert plonk.create_proof(ctx, pk, inst, d_adv, seed=seed, transcript=plonk.MULTIOPEN_GWC) == PR.create_proof(opk, c.instances, c.advice, seed=seed, multiopen="gwc")
     d_adv.free(); pk.free(); params.free()
+
+
+MULTI_CASES = [(5, s, 2) for s in range(200, 212)] + [(6, s, 3) for s in range(212, 220)] + [(7, s, 2) for s in range(220, 224)]
+
+
+@pytest.mark.parametrize("k,seed,ncirc", MULTI_CASES[::3])
+def test_oracle_multi_instance_proofs_verify_on_random_circuits(plonk, k, seed, ncirc):
+    c = circuits.random_circuit(plonk, k, seed)
+    wit = [(c.advice, c.instances)] + [c.witness(j) for j in range(1, ncirc)]
+    opk = PR.keygen(c.desc, c.fixed, c.assembly.mapping, TAU, transcript_repr=99)
+    try:
+        proof = PR.create_proof_multi(opk, [i for _, i in wit], [a for a, _ in wit], seed=seed)
+    except AssertionError as e:
+        assert "infinity" in str(e)
+        return
+    assert PR.verify_proof_multi(opk, [i for _, i in wit], proof)
+    if wit[0][1] != wit[-1][1]:  # the public inputs differ: their order is part of the statement
+        with pytest.raises(AssertionError):
+            PR.verify_proof_multi(opk, [i for _, i in wit][::-1], proof)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,seed,ncirc", MULTI_CASES)
+def test_device_multi_instance_proofs_equal_oracle_on_random_circuits(ctx, pkg, plonk, oracle, k, seed, ncirc):
+    """upstream's slices on random constraint systems: N witnesses of one random layout in one proof (amdzk_create_proof_multi)."""
+    c = circuits.random_circuit(plonk, k, seed)
+    wit = [(c.advice, c.instances)] + [c.witness(j) for j in range(1, ncirc)]
+    if k not in _srs:
+        _srs[k] = zu.test_srs(oracle, k, TAU)
+    g, gl = _srs[k]
+    params = pkg.kzg.ParamsKZG(ctx, k, g=g, g_lagrange=gl)
+    fixed = np.stack([zu.ints_to_fr(oracle, col) for col in c.fixed])
+    pk = plonk.ProvingKey(ctx, params, c.desc, fixed, c.assembly.mapping, zu.fr_from_int(99))
+    pks = [pk] + [pk.clone_workspace() for _ in range(1, ncirc)]
+    d_adv, inst = [], []
+    for a, i in wit:
+        arr = np.stack([zu.ints_to_fr(oracle, col) for col in a])
+        d_adv.append(ctx.alloc(arr.nbytes).upload(arr))
+        inst.append([zu.ints_to_fr(oracle, col) if col else np.zeros((0, 4), np.uint64) for col in i])
+    tr = "evm" if seed % 3 == 0 else "blake2b"
+    trn = plonk.TRANSCRIPT_KECCAK256_EVM if tr == "evm" else plonk.TRANSCRIPT_BLAKE2B
+    opk = PR.keygen(c.desc, c.fixed, c.assembly.mapping, TAU, transcript_repr=99)
+    try:
+        want = PR.create_proof_multi(opk, [i for _, i in wit], [a for a, _ in wit], seed=seed, transcript=tr)
+    except AssertionError as e:
+        assert "infinity" in str(e)
+        with pytest.raises(pkg.ffi.AmdzkError, match="infinity"):
+            plonk.create_proof_multi(ctx, pks, inst, d_adv, seed=seed, transcript=trn)
+        want = None
+    if want is not None:
+        assert plonk.create_proof_multi(ctx, pks, inst, d_adv, seed=seed, transcript=trn) == want
+        assert plonk.create_proof_multi(ctx, pks, inst, d_adv, seed=seed, transcript=trn) == want
+    for d in d_adv:
+        d.free()
+    for q in pks[1:]:
+        q.free()
+    pk.free(); params.free()
