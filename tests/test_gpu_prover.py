@@ -454,3 +454,54 @@ def test_several_circuit_instances_in_one_proof(ctx, pkg, plonk, oracle, k, ncir
     for q in pks[1:]:
         q.free()
     pk.free(); params.free()
+
+
+def test_create_proof_argument_errors_leave_the_context_usable(ctx, pkg, plonk, oracle):
+    """The error half of the boundary (`int` return, message via amdzk_last_error, never aborts): every
+    refused call names its reason, and the same context and key prove the right bytes afterwards.
+      * an instance column longer than the usable rows — upstream's Error::InstanceTooLarge
+      * a null advice pointer, an advice stride < n, an unknown transcript kind, a null instance column with a length
+      * a proof buffer that is too small: refused, with the needed length reported in *proof_len
+      * proof_out = NULL: the length query"""
+    import ctypes as C
+    c = circuits.lookup_circuit(plonk, 6, seed=4)
+    params, pk, d_adv, inst = setup(ctx, pkg, plonk, oracle, c)
+    opk = PR.keygen(c.desc, c.fixed, c.assembly.mapping, TAU, transcript_repr=123456789)
+    want = PR.create_proof(opk, c.instances, c.advice, seed=3)
+    n = c.n
+
+    def good():
+        assert plonk.create_proof(ctx, pk, inst, d_adv, seed=3) == want
+
+    good()
+    too_long = [np.zeros((c.usable + 1, 4), np.uint64)] + list(inst[1:])
+    with pytest.raises(pkg.AmdzkError, match="InstanceTooLarge"):
+        plonk.create_proof(ctx, pk, too_long, d_adv, seed=3)
+    good()
+    with pytest.raises(pkg.AmdzkError, match="null"):
+        plonk.create_proof(ctx, pk, inst, None, seed=3)
+    with pytest.raises(pkg.AmdzkError, match="stride"):
+        plonk.create_proof(ctx, pk, inst, d_adv, seed=3, advice_stride=n - 1)
+    with pytest.raises(pkg.AmdzkError, match="transcript"):
+        plonk.create_proof(ctx, pk, inst, d_adv, seed=3, transcript=7)
+    good()
+    # raw calls: a null instance column with a non-zero length; buffer too small; length query
+    L = ctx.L
+    cols = [np.ascontiguousarray(x, dtype=np.uint64).reshape(-1, 4) for x in inst]
+    ptrs = (C.c_void_p * len(cols))(*[x.ctypes.data if x.size else None for x in cols])
+    lens = (C.c_size_t * len(cols))(*[x.shape[0] for x in cols])
+    need = C.c_size_t(0)
+    buf = (C.c_uint8 * (1 << 16))()
+    null_ptrs = (C.c_void_p * len(cols))()
+    one = (C.c_size_t * len(cols))(*([1] * len(cols)))
+    assert L.amdzk_create_proof_ex(ctx.h, pk.h, null_ptrs, one, d_adv.ptr, n, C.c_uint64(3), 0, buf, len(buf), C.byref(need)) != 0
+    assert b"null" in L.amdzk_last_error(ctx.h)
+    need.value = 0
+    assert L.amdzk_create_proof_ex(ctx.h, pk.h, ptrs, lens, d_adv.ptr, n, C.c_uint64(3), 0, buf, 16, C.byref(need)) != 0
+    assert b"too small" in L.amdzk_last_error(ctx.h) and need.value == len(want)
+    need.value = 0
+    assert L.amdzk_create_proof_ex(ctx.h, pk.h, ptrs, lens, d_adv.ptr, n, C.c_uint64(3), 0, None, 0, C.byref(need)) == 0
+    assert need.value == len(want) == plonk.proof_size(ctx, pk)
+    assert L.amdzk_create_proof_ex(ctx.h, pk.h, ptrs, lens, d_adv.ptr, n, C.c_uint64(3), 0, buf, len(buf), C.byref(need)) == 0
+    assert bytes(buf[: need.value]) == want
+    d_adv.free(); pk.free(); params.free()
