@@ -124,8 +124,10 @@ def rsa_sha256_shape(k=15, seed=7, num_advice=80, num_lookup_advice=16, lookup_b
     lay = np.random.RandomState(layout_seed)
     used = set()  # every cell takes part in at most one copy, so fixing up a copied-to cell never disturbs another
 
+    used_in = {}  # gate column -> cells of it in `used`
+
     def free_gate(ci):
-        if ngates <= 0 or sum(1 for (cc, r) in used if cc == ci) >= 4 * ngates:
+        if ngates <= 0 or used_in.get(ci, 0) >= 4 * ngates:
             raise ValueError("rsa_sha256_shape: k = %d with %d gate columns has too few gate rows for the layout's copy constraints "
                              "(it needs 72 free gates, column %d is full): use a larger k or more columns" % (k, num_advice, ci))
         while True:
@@ -133,6 +135,7 @@ def rsa_sha256_shape(k=15, seed=7, num_advice=80, num_lookup_advice=16, lookup_b
             if all((ci, 4 * g + o) not in used for o in range(4)):
                 for o in range(4):
                     used.add((ci, 4 * g + o))
+                used_in[ci] = used_in.get(ci, 0) + 4
                 return 4 * g
 
     # assignments applied to every witness, in order: ("gate", ci, r0, off, source) sets gate input `off` of the gate
