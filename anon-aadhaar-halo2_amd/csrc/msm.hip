@@ -1428,8 +1428,8 @@ static MsmGeom msm_geometry(const amdzk_srs* srs, size_t ncols, size_t len, size
   if (e_total > (size_t)4 * 262144) g.T1 = 8;
   if (e_total > (size_t)8 * 262144) g.T1 = 12;
   // one long column (k >= 19): tens of millions of entries keep the chip full whatever the task size, and every partial
-  // sum a task leaves behind is one more addition in the folds (profiles/r04a_*: 2^22 points, T1 = 12 / 24 / 32 / 48)
-  if (g.ecap >= ((size_t)1 << 23)) g.T1 = 32;
+  // sum a task leaves behind is one more addition in the folds (profiles/r04a_*: 2^22 points, T1 = 12 / 24 / 32 / 48 / 64: 7.48 / 7.44 / 7.36 / 7.32 / 7.28 ms)
+  if (g.ecap >= ((size_t)1 << 23)) g.T1 = g.ecap >= ((size_t)1 << 25) ? 64 : 32;  // 2^19 points: 1.53 ms with 32, 1.69 with 64; 2^22: 7.33 / 7.14
   if (const char* e = getenv("AMDZK_MSM_T1")) g.T1 = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : g.T1;
   g.TL = 6;  // 4 / 6 / 8 / 12 / 16 prove at the same rate (76.7-78.0 proofs/s); 6 has the shortest proof (profiles/r02j_msm_task_size.txt)
   if (const char* e = getenv("AMDZK_MSM_TL")) g.TL = (uint32_t)atoi(e) > 1 ? (uint32_t)atoi(e) : g.TL;

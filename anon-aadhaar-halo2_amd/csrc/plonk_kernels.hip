@@ -1155,6 +1155,24 @@ int amdzk_batch_invert_dev(amdzk_ctx* ctx, void* d_a, size_t n) {
   return zk_batch_invert(ctx, (Fr*)d_a, scratch, n);
 }
 
+// poly::batch_invert_assigned [UP] on the device — the step between Circuit::synthesize and the advice commitments
+// (SURVEY.md Appendix A step 3): a cell is Assigned::Rational(numerator, denominator) (Trivial(x) = (x, 1), Zero = (0, 1)) and
+// evaluates to numerator * denominator^-1, with a zero denominator giving zero (BatchInvert leaves zeros, as upstream's
+// `invert().unwrap_or(zero)`). d_den == NULL: every cell is trivial. d_out may be d_num (in place); it must not overlap d_den.
+int amdzk_batch_invert_assigned_dev(amdzk_ctx* ctx, const void* d_num, const void* d_den, size_t n, void* d_out) {
+  ZK_ENTER(ctx);
+  if (!ctx) return AMDZK_E_INVALID;
+  if (n && (!d_num || !d_out)) ZK_FAIL(ctx, AMDZK_E_INVALID, "batch_invert_assigned: null pointer");
+  if (!n) return AMDZK_OK;
+  if (d_out != d_num) ZK_HIP(ctx, hipMemcpyAsync(d_out, d_num, n * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+  if (!d_den) return AMDZK_OK;
+  Fr* ws = nullptr;
+  ZK_TRY(zk_ws_reserve(ctx, 7, 2 * n * sizeof(Fr), (void**)&ws));
+  ZK_HIP(ctx, hipMemcpyAsync(ws, d_den, n * sizeof(Fr), hipMemcpyDeviceToDevice, ctx->stream));
+  ZK_TRY(zk_batch_invert(ctx, ws, ws + n, n));
+  return zk_mul_elem(ctx, (Fr*)d_out, ws, n);
+}
+
 // The running product of permutation::prover::Argument::commit / lookup::prover::commit_product: column c of
 // d_cols (n elements at + c * col_stride) is replaced by z with z[0] = 1, z[i] = z[i-1] * f[i-1]. chain != 0 threads the
 // permutation argument's last_z through the columns: z_c[0] = z_{c-1}[chain_row] instead of 1.

@@ -91,6 +91,7 @@ def lib():
         "amdzk_create_proof_scalars": (i32, [vp, vp, C.POINTER(vp), C.POINTER(sz), vp, sz, vp, sz, i32, vp, sz, C.POINTER(sz)]),
         "amdzk_ntt_fr_batch": (i32, [vp, C.POINTER(vp), sz, u32, vp, u32]),
         "amdzk_batch_invert_dev": (i32, [vp, vp, sz]),
+        "amdzk_batch_invert_assigned_dev": (i32, [vp, vp, vp, sz, vp]),
         "amdzk_grand_product_dev": (i32, [vp, vp, sz, sz, sz, i32, sz]),
         "amdzk_eval_poly_dev": (i32, [vp, C.POINTER(vp), vp, sz, u32, vp]),
         "amdzk_poly_axpy_dev": (i32, [vp, C.POINTER(vp), vp, sz, vp, sz, i32]),

@@ -86,6 +86,29 @@ def batch_invert(ctx, a):
     return out
 
 
+def batch_invert_assigned(ctx, numerators, denominators=None, in_place=False):
+    """poly::batch_invert_assigned: Assigned::Rational(num, den) cells -> num * den^-1 (zero where den = 0); denominators=None:
+    every cell Trivial."""
+    num = as_fr_array(numerators)
+    n = num.shape[0]
+    d_num = ctx.alloc(max(1, num.nbytes)).upload(num)
+    d_den = None
+    if denominators is not None:
+        den = as_fr_array(denominators)
+        assert den.shape[0] == n
+        d_den = ctx.alloc(max(1, den.nbytes)).upload(den)
+    d_out = d_num if in_place else ctx.alloc(max(1, num.nbytes))
+    ctx._chk(ctx.L.amdzk_batch_invert_assigned_dev(ctx.h, d_num.ptr, d_den.ptr if d_den is not None else None, n, d_out.ptr))
+    out = d_out.download(num.shape)
+    if not in_place:
+        assert np.array_equal(d_num.download(num.shape), num)  # the numerators are read, not written
+        d_out.free()
+    d_num.free()
+    if d_den is not None:
+        d_den.free()
+    return out
+
+
 def grand_product(ctx, cols, chain=False, chain_row=0):
     """Running products z[0] = 1, z[i] = z[i-1] * f[i-1] of every column (permutation / lookup commit_product);
     chain: z_c[0] = z_{c-1}[chain_row]."""

@@ -309,6 +309,10 @@ int amdzk_create_proof_scalars(amdzk_ctx* ctx, amdzk_pk* pk, const uint64_t* con
  * for the isolated parity tests (tests/test_gpu_plonk_ops.py). Small operands come from the host. */
 /* ff::BatchInvert [UP] in place: non-zero elements are inverted, zeros stay zero. */
 int amdzk_batch_invert_dev(amdzk_ctx* ctx, void* d_a, size_t n);
+/* poly::batch_invert_assigned [UP] (what create_proof does to the synthesized Assigned<F> cells before it commits to them,
+ * SURVEY.md Appendix A step 3): out[i] = num[i] * den[i]^-1, zero where den[i] = 0. A Trivial cell is (x, 1), Zero is (0, 1);
+ * d_den = NULL means all cells are trivial. In place (d_out = d_num) is allowed. */
+int amdzk_batch_invert_assigned_dev(amdzk_ctx* ctx, const void* d_num, const void* d_den, size_t n, void* d_out);
 /* The running product of permutation::prover::Argument::commit and lookup::prover::commit_product [UP]: column c
  * (n elements at d_cols + c*col_stride) is replaced by z with z[0] = 1, z[i] = z[i-1] * f[i-1]; with chain != 0 the
  * permutation argument's last_z is threaded through the columns: z_c[0] = z_{c-1}[chain_row]. */

@@ -52,6 +52,29 @@ def test_batch_invert(ctx, ar, oracle, n):
     assert not got[::7].any()
 
 
+@pytest.mark.parametrize("n", [0, 1, 129, 4097, 70001])
+def test_batch_invert_assigned(ctx, ar, oracle, n):
+    """poly::batch_invert_assigned (SURVEY.md Appendix A step 3): Rational cells with random, unit (Trivial) and ZERO
+    denominators against Python integers — num * den^-1 mod r, zero for a zero denominator — out of place, in place, and with
+    no denominators at all."""
+    import random
+    rnd = random.Random(300 + n)
+    nums = [rnd.randrange(zu.R) for _ in range(n)]
+    dens = [rnd.randrange(1, zu.R) for _ in range(n)]
+    for i in range(n):
+        if i % 5 == 0:
+            dens[i] = 1
+        elif i % 11 == 3:
+            dens[i] = 0
+        if i % 13 == 7:
+            nums[i] = 0
+    want = [a * pow(d, zu.R - 2, zu.R) % zu.R for a, d in zip(nums, dens)]
+    fa, fd, fw = (zu.ints_to_fr(oracle, v).reshape(-1, 4) for v in (nums, dens, want))
+    assert np.array_equal(ar.batch_invert_assigned(ctx, fa, fd), fw)
+    assert np.array_equal(ar.batch_invert_assigned(ctx, fa, fd, in_place=True), fw)
+    assert np.array_equal(ar.batch_invert_assigned(ctx, fa, None), fa)
+
+
 @pytest.mark.parametrize("n,ncols", [(1, 1), (7, 3), (2047, 2), (2048, 2), (2049, 3), (5000, 3)])
 def test_grand_product_plain_and_chained(ctx, ar, oracle, n, ncols):
     """SCAN_BLOCK is 2048 elements: sizes below, at, just above and not a multiple of it; with and without the
