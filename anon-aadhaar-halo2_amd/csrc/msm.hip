@@ -1432,6 +1432,20 @@ static MsmGeom msm_geometry(const amdzk_srs* srs, size_t ncols, size_t len, size
   if (g.ecap >= ((size_t)1 << 23)) g.T1 = g.ecap >= ((size_t)1 << 25) ? 64 : 32;  // 2^19 points: 1.53 ms with 32, 1.69 with 64; 2^22: 7.33 / 7.14
   if (const char* e = getenv("AMDZK_MSM_T1")) g.T1 = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : g.T1;
   g.TL = 6;  // 4 / 6 / 8 / 12 / 16 prove at the same rate (76.7-78.0 proofs/s); 6 has the shortest proof (profiles/r02j_msm_task_size.txt)
+  {
+    // ... unless the FULLEST buckets of a uniform column would then reach the per-bucket final with more than FINAL_SERIAL partial
+    // sums. The top window of a 254-bit scalar has few digits — (r >> c (W - 1)) + 1 of them: 97 at c = 13 — so those buckets
+    // hold len / 97 entries on top of the average len W / nb, they are neighbours (one wavefront of msm_accum_final), and each
+    // takes that wavefront through the cooperative path in turn: at 2^18 points (3,983 entries in each of them) the final
+    // kernel was 1.48 ms of a 2.33 ms MSM and 10.4 ms of the k = 18 proof (profiles/r04x_k18_top_window_buckets.txt). Two
+    // folds of TL must bring the fullest bucket's T1-sums down to ~4: TL = 7 at 2^17, 9 at 2^18; 6 up to 2^16 and for c >= 15.
+    const unsigned top_shift = g.c * (g.W - 1);
+    const uint64_t r_top = 0x30644e72e131a029ULL;  // the scalar field's modulus, bits 192..255 (contract.sol:211)
+    const double top_digits = top_shift >= 192 && top_shift < 256 ? (double)((r_top >> (top_shift - 192)) + 1) : (double)g.nb;
+    const double fullest = (double)len * g.W / g.nb + (double)len / std::min<double>(top_digits, (double)g.nb);
+    if (top_digits >= 8)  // two or four such buckets (c = 11, 12) cost 40 us each in the final: not worth wider folds
+      while (g.TL < 16 && fullest / g.T1 / ((double)g.TL * g.TL) > 4.5) g.TL++;
+  }
   if (const char* e = getenv("AMDZK_MSM_TL")) g.TL = (uint32_t)atoi(e) > 1 ? (uint32_t)atoi(e) : g.TL;
   // Folding levels: two (TL = 6) in front of the per-bucket final. ONE fold (AMDZK_MSM_NLEV=2, with TL = max(6, partial
   // sums per bucket / 4)) was measured in round 4 and is a trap: the AVERAGE bucket of a proof-sized MSM then reaches the
