@@ -859,9 +859,10 @@ __global__ __launch_bounds__(256) void lookup_mark_kernel(const Fr* A, const Fr*
 }
 
 // out[i] = number of set (invert = 0) / clear (invert = 1) flags before i, i < cnt; out[cnt] = total. One workgroup per
-// column walks it in tiles of 4096 flags — four consecutive flags per lane, so a wavefront's loads cover 1 KiB of
+// column walks it in tiles of 8192 flags — eight consecutive flags per lane, so a wavefront's loads cover 2 KiB of
 // contiguous memory (a lane used to own cnt / 1024 consecutive flags: 64 cache lines per load, 0.37 ms per launch at
 // 2^18 rows) — with a shuffle scan per wavefront, the 16 wavefront totals through LDS and a running carry between tiles.
+constexpr int FS_PER = 8;
 __global__ __launch_bounds__(1024) void flag_scan_kernel(const uint32_t* flags, uint32_t* out, uint32_t cnt, size_t stride, int invert) {
   __shared__ uint32_t wsum[2][16];
   const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
@@ -869,11 +870,11 @@ __global__ __launch_bounds__(1024) void flag_scan_kernel(const uint32_t* flags, 
   uint32_t* o = out + (size_t)blockIdx.x * stride;
   uint32_t carry = 0;
   int buf = 0;
-  for (uint32_t base = 0; base < cnt; base += 4096, buf ^= 1) {
-    const uint32_t i0 = base + 4 * t;
-    uint32_t v[4], s = 0;
+  for (uint32_t base = 0; base < cnt; base += 1024 * FS_PER, buf ^= 1) {
+    const uint32_t i0 = base + FS_PER * t;
+    uint32_t v[FS_PER], s = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < FS_PER; k++) {
       const uint32_t idx = i0 + k;
       const uint32_t bit = idx < cnt ? (f[idx] ? 1u : 0u) : 0u;
       v[k] = idx < cnt ? (invert ? 1u - bit : bit) : 0u;
@@ -896,7 +897,7 @@ __global__ __launch_bounds__(1024) void flag_scan_kernel(const uint32_t* flags, 
     }
     uint32_t run = carry + before + inc - s;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < FS_PER; k++) {
       if (i0 + k < cnt) o[i0 + k] = run;
       run += v[k];
     }
