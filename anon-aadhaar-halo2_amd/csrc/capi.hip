@@ -376,7 +376,7 @@ int amdzk_dev_upload_async(amdzk_ctx* ctx, void* dptr, const void* host, size_t 
   if (bytes) {
     ZK_HIP(ctx, hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
     // the completion marker travels with the copy (not with the fence): by the time a pipelined caller fences, the copy
-    // queue has long gone idle, and a marker sent to an idle queue is only seen when the hardware scheduler next maps it
+    // queue has long gone idle, and a marker sent to an idle queue completes only when that queue is next serviced
     ZK_HIP(ctx, hipEventRecord(ctx->copy_evt, ctx->copy_stream));
     ctx->copy_pending = true;
   }
@@ -384,8 +384,8 @@ int amdzk_dev_upload_async(amdzk_ctx* ctx, void* dptr, const void* host, size_t 
 }
 // Order the context's stream behind its uploads. A caller that overlaps the next witness's upload with the current proof
 // (feeder.py) fences a copy that finished long ago: the host sees that with one event query and the proof's stream gets NO
-// cross-queue dependency. (With one in front of every proof, eight proofs that run in step all stalled on the hardware
-// scheduler at the same moment: 5-10 % of the rate in some timed regions, profiles/r04y_streamed_regions_in_step.txt.)
+// cross-queue dependency. (With one in front of every proof, eight proofs that run in step all waited on such a marker at the
+// same moment and some timed regions ran 5-10 % low with the chip partly idle: profiles/r04y_streamed_regions_in_step.txt.)
 // Only a copy still in flight is waited for, on the device.
 int amdzk_upload_fence(amdzk_ctx* ctx) {
   ZK_ENTER(ctx);
