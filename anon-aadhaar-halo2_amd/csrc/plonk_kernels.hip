@@ -543,7 +543,10 @@ __device__ __forceinline__ Fr29 pe_pow(const Fr29& base, uint32_t e, int bits) {
   }
   return r;
 }
-__global__ __launch_bounds__(PE_T) void poly_eval_kernel(const Fr* const* polys, const Fr* points, Fr* out, uint32_t n) {
+// gridDim.y > 1 (polynomials longer than 2^16): workgroup (q, seg) evaluates segment seg alone — v_seg = sum over its 2^16
+// coefficients c[2^16 seg + i] x^i — into parts[q * gridDim.y + seg], and poly_eval_combine_kernel folds the segments with
+// x^(2^16): a k = 18 proof's ~120 queries were 120 workgroups walking four segments each, 0.79 ms on an otherwise idle chip.
+__global__ __launch_bounds__(PE_T) void poly_eval_kernel(const Fr* const* polys, const Fr* points, Fr* out, uint32_t n, Fr* parts) {
   __shared__ uint32_t XP[PE_T][9];   // (x^256)^j
   __shared__ uint32_t XA[16][9], XB[16][9];  // x^a, (x^16)^b
   __shared__ Fr red[PE_T];
@@ -582,8 +585,9 @@ __global__ __launch_bounds__(PE_T) void poly_eval_kernel(const Fr* const* polys,
     Fr29 acc;
 #pragma unroll
     for (int i = 0; i < 9; i++) acc.l[i] = 0;
+    const bool split = gridDim.y > 1;
 #pragma unroll 1
-    for (uint32_t seg = nseg; seg-- > 0;) {
+    for (uint32_t seg = split ? blockIdx.y + 1 : nseg; seg-- > (split ? blockIdx.y : 0u);) {
       F29Wide w;
       f29_wide_zero(w);
       const uint32_t j0 = seg * PE_T, jn = (J - j0) < PE_T ? (J - j0) : PE_T;
@@ -596,7 +600,7 @@ __global__ __launch_bounds__(PE_T) void poly_eval_kernel(const Fr* const* polys,
       f29_wide_carry(w);
       const Fr29 part = f29_wide_redc<Fr29P>(w);  // below 256 * 2 / 169.3 + 1 < 4.1 p
       // segments from the top down: acc = acc * (x^256)^256 + part; acc below 2 + 4.1
-      acc = seg + 1 == nseg ? part : f29_add(f29_mul(acc, xbig), part);
+      acc = (split || seg + 1 == nseg) ? part : f29_add(f29_mul(acc, xbig), part);
     }
     Fr29 xa, xb;
 #pragma unroll
@@ -613,7 +617,19 @@ __global__ __launch_bounds__(PE_T) void poly_eval_kernel(const Fr* const* polys,
     if (t < d) red[t] = add(red[t], red[t + d]);
     __syncthreads();
   }
-  if (t == 0) st_fr(out + q, red[0]);
+  if (t == 0) st_fr(gridDim.y > 1 ? parts + (size_t)q * gridDim.y + blockIdx.y : out + q, red[0]);
+}
+// out[q] = sum_seg parts[q][seg] * (x_q^65536)^seg, Horner from the top segment down; one lane per query (a handful of products).
+__global__ __launch_bounds__(64) void poly_eval_combine_kernel(const Fr* parts, const Fr* points, Fr* out, uint32_t nq, uint32_t nseg) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  Fr xb = ld_fr(points + q);
+#pragma unroll 1
+  for (int i = 0; i < 16; i++) xb = mul(xb, xb);
+  Fr acc = ld_fr(parts + (size_t)q * nseg + nseg - 1);
+#pragma unroll 1
+  for (uint32_t seg = nseg - 1; seg-- > 0;) acc = add(mul(acc, xb), ld_fr(parts + (size_t)q * nseg + seg));
+  st_fr(out + q, acc);
 }
 
 // ------------------------------------------------------------------------------ linear combinations
@@ -859,10 +875,10 @@ __global__ __launch_bounds__(256) void lookup_mark_kernel(const Fr* A, const Fr*
 }
 
 // out[i] = number of set (invert = 0) / clear (invert = 1) flags before i, i < cnt; out[cnt] = total. One workgroup per
-// column walks it in tiles of 8192 flags — eight consecutive flags per lane, so a wavefront's loads cover 2 KiB of
+// column walks it in tiles of 4096 flags — four consecutive flags per lane, so a wavefront's loads cover 1 KiB of
 // contiguous memory (a lane used to own cnt / 1024 consecutive flags: 64 cache lines per load, 0.37 ms per launch at
 // 2^18 rows) — with a shuffle scan per wavefront, the 16 wavefront totals through LDS and a running carry between tiles.
-constexpr int FS_PER = 8;
+constexpr int FS_PER = 4;  // 8 per lane measured slower (0.45 against 0.30 ms per k = 18 proof)
 __global__ __launch_bounds__(1024) void flag_scan_kernel(const uint32_t* flags, uint32_t* out, uint32_t cnt, size_t stride, int invert) {
   __shared__ uint32_t wsum[2][16];
   const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
@@ -1029,7 +1045,17 @@ int zk_running_product(amdzk_ctx* ctx, Fr* d_cols, size_t ncols, size_t n, size_
 }
 
 int zk_poly_eval(amdzk_ctx* ctx, const Fr* const* d_polys, const Fr* d_points, Fr* d_out, size_t nq, uint32_t n) {
-  if (nq) ZK_LAUNCH(ctx, "poly_eval", poly_eval_kernel, dim3((unsigned)nq), dim3(256), 0, d_polys, d_points, d_out, n);
+  if (!nq) return AMDZK_OK;
+  const uint32_t nseg = (n + 65535u) / 65536u;  // PE_T lanes x PE_T power-table entries per segment
+  if (nseg <= 1 || nq > 65535) {
+    ZK_LAUNCH(ctx, "poly_eval", poly_eval_kernel, dim3((unsigned)nq), dim3(256), 0, d_polys, d_points, d_out, n, (Fr*)nullptr);
+    return AMDZK_OK;
+  }
+  Fr* parts = nullptr;
+  ZK_TRY(zk_ws_reserve(ctx, 4, nq * nseg * sizeof(Fr), (void**)&parts));  // slot 4 is also kate_div's and lincomb's: stream order keeps them apart
+  ZK_LAUNCH(ctx, "poly_eval", poly_eval_kernel, dim3((unsigned)nq, nseg), dim3(256), 0, d_polys, d_points, d_out, n, parts);
+  ZK_LAUNCH(ctx, "poly_eval_combine", poly_eval_combine_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(64), 0, (const Fr*)parts, d_points, d_out, (uint32_t)nq,
+            nseg);
   return AMDZK_OK;
 }
 

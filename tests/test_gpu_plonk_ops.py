@@ -101,8 +101,10 @@ def test_grand_product_plain_and_chained(ctx, ar, oracle, n, ncols):
         start = want[u]
 
 
-@pytest.mark.parametrize("n", [1, 2, 255, 256, 257, 4096])
+@pytest.mark.parametrize("n", [1, 2, 255, 256, 257, 4096, 65536, 65537, 70000, 131072, 262144 + 77])
 def test_eval_polynomial(ctx, ar, oracle, n):
+    """Above 2^16 coefficients a query is cut into segments of 2^16 evaluated by separate workgroups and folded with x^(2^16)
+    (poly_eval_combine_kernel): sizes at, just above and well above one, two and four segments, ragged last segments."""
     polys = [zu.random_fr(n, seed=300 + n + i) for i in range(5)]
     pts = zu.random_fr(5, seed=77 + n)
     pts[0] = 0
