@@ -507,25 +507,40 @@ def test_create_proof_argument_errors_leave_the_context_usable(ctx, pkg, plonk, 
     d_adv.free(); pk.free(); params.free()
 
 
-@pytest.mark.parametrize("env", [
+SWITCHES = [
     {"AMDZK_LATENCY_MODE": "0"}, {"AMDZK_LATENCY_COLS": "64"}, {"AMDZK_FOLD_QUAD": "0"}, {"AMDZK_TAIL_QUAD": "0", "AMDZK_TAIL_TREE": "1"},
     {"AMDZK_MSM_NLEV": "2"}, {"AMDZK_L1_LDS": "4"}, {"AMDZK_L1_LDS": "9"}, {"AMDZK_SERIAL": "1"}, {"AMDZK_FULL_COSETS": "1"},
     {"AMDZK_HOST_WAIT": "block"}, {"AMDZK_H_PARTS": "1"}, {"AMDZK_MSM_T1": "32", "AMDZK_MSM_TL": "4"}, {"AMDZK_MSM_PIPELINE": "0"},
-    {"AMDZK_NTT_AFTER_L1": "0"}, {"AMDZK_MSM_C": "12"}])
-def test_whole_proofs_under_every_documented_switch(env):
+    {"AMDZK_NTT_AFTER_L1": "0"}, {"AMDZK_MSM_C": "12"}]
+
+
+def test_whole_proofs_under_every_documented_switch():
     """INTEGRATION.md's environment switches — the variants kept behind them (latency mode off / wider, one fold level, level 1
     with the accumulator in LDS or as a persistent grid, serial or full-coset default keys, polling waits, one-piece h(X)
     program, other task sizes and window width, no pipelining) prove the oracle's BYTES: whole-proof tests of this file and a
-    few random constraint systems, again, in a child process with the switch forced (switches are read once per process)."""
+    few random constraint systems, again, in child processes with the switch forced (switches are read once per process).
+    Four children at a time (with this process, five on the GPU: the pool allows six)."""
     import subprocess
-    e = dict(os.environ)
-    e.update(env)
     here = os.path.dirname(os.path.abspath(__file__))
     gp, rc = os.path.join(here, "test_gpu_prover.py"), os.path.join(here, "test_random_circuits.py")
     ids = [gp + "::test_proof_bytes_equal_oracle", gp + "::test_rsa_sha256_shape_small_equals_oracle",
            gp + "::test_several_circuit_instances_in_one_proof[7-2-blake2b]"]  # GWC: the random circuits with seed % 4 == 1
     ids += [rc + "::test_device_proof_bytes_equal_oracle_on_random_circuits[%s]" % c for c in ("5-1", "5-9", "6-44", "6-23", "7-85", "8-112", "9-120")]
     ids += [rc + "::test_device_multi_instance_proofs_equal_oracle_on_random_circuits[6-212-3]"]
-    r = subprocess.run([sys.executable, "-m", "pytest", *ids, "-x", "-q", "-m", "gpu"], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
-    assert r.returncode == 0, "%r:\n%s" % (env, r.stdout[-3000:])
-    assert " passed" in r.stdout and "failed" not in r.stdout
+    pending, running, failed = list(SWITCHES), [], []
+    while pending or running:
+        while pending and len(running) < 4:
+            env = pending.pop(0)
+            e = dict(os.environ)
+            e.update(env)
+            running.append((env, subprocess.Popen([sys.executable, "-m", "pytest", *ids, "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"], env=e,
+                                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        env, proc = running.pop(0)
+        try:
+            out, _ = proc.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            out = "timed out\n" + proc.communicate()[0]
+        if proc.returncode != 0 or " passed" not in out or "failed" in out:
+            failed.append((env, out[-2000:]))
+    assert not failed, "\n\n".join("%r:\n%s" % f for f in failed)
